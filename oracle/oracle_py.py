@@ -1,0 +1,107 @@
+"""ctypes binding of this repo's CPU restatement (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from zlib_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+class Token(C.Structure):
+    _fields_ = [("dist", C.c_uint16), ("lc", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class ChunkInfo(C.Structure):
+    _fields_ = [("ntokens", C.c_uint32), ("nblocks", C.c_uint32), ("btype", C.c_uint32 * 8),
+                ("data_type", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.ora_deflate_chunk.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p]
+        L.ora_deflate_chunk.restype = C.c_size_t
+        L.ora_deflate_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ora_deflate_stream.restype = C.c_size_t
+        L.ora_deflate_bound.argtypes = [C.c_size_t, C.c_size_t]
+        L.ora_deflate_bound.restype = C.c_size_t
+        L.ora_adler32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+        L.ora_adler32.restype = C.c_uint32
+        L.ora_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.ora_adler32_combine.restype = C.c_uint32
+        L.ora_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+        L.ora_crc32.restype = C.c_uint32
+        for f in (L.ora_inflate_raw, L.ora_inflate_zlib):
+            f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                          C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
+            f.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def deflate_chunk(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False, want_tokens=False):
+    L = lib()
+    cap = len(chunk) + 512
+    out = C.create_string_buffer(cap)
+    info = ChunkInfo()
+    toks = (Token * max(len(chunk), 1))() if want_tokens else None
+    n = L.ora_deflate_chunk(chunk, len(chunk), level, int(pos0_matchable), int(is_last), out, cap,
+                            C.cast(toks, C.c_void_p) if want_tokens else None, C.byref(info))
+    if n == 0:
+        raise RuntimeError("oracle deflate_chunk failed")
+    if want_tokens:
+        return out.raw[:n], info, [(toks[i].dist, toks[i].lc) for i in range(info.ntokens)]
+    return out.raw[:n]
+
+
+def deflate_stream(data, level: int, chunk: int = 65536) -> bytes:
+    """data: bytes or a numpy uint8 array (no copy)."""
+    L = lib()
+    n = len(data)
+    cap = L.ora_deflate_bound(n, chunk)
+    out = C.create_string_buffer(cap)
+    if isinstance(data, (bytes, bytearray)):
+        src = C.cast(C.c_char_p(bytes(data)), C.c_void_p)
+    else:
+        src = C.c_void_p(data.ctypes.data)
+    got = L.ora_deflate_stream(src, n, level, chunk, out, cap)
+    if got == 0:
+        raise RuntimeError("oracle deflate_stream failed")
+    return out.raw[:got]
+
+
+def adler32(data: bytes, start: int = 1) -> int:
+    return lib().ora_adler32(start, data, len(data))
+
+
+def adler32_combine(a1, a2, len2):
+    return lib().ora_adler32_combine(a1, a2, len2)
+
+
+def crc32(data: bytes, start: int = 0) -> int:
+    return lib().ora_crc32(start, data, len(data))
+
+
+def _inflate(fn, data: bytes, outcap: int):
+    out = C.create_string_buffer(max(outcap, 1))
+    used, prod, msg = C.c_size_t(0), C.c_size_t(0), C.c_char_p()
+    rc = fn(data, len(data), out, outcap, C.byref(used), C.byref(prod), C.byref(msg))
+    return rc, out.raw[:prod.value], used.value, (msg.value.decode() if msg.value else None)
+
+
+def inflate_raw(data: bytes, outcap: int):
+    return _inflate(lib().ora_inflate_raw, data, outcap)
+
+
+def inflate_zlib(data: bytes, outcap: int):
+    return _inflate(lib().ora_inflate_zlib, data, outcap)
