@@ -1,0 +1,81 @@
+"""Pins the CPU restatement directly to the compiled reference (oracle/_ref/libzref.so).  Skipped when
+that build is absent (a checkout without /root/reference and without a prebuilt _ref/)."""
+import pytest
+
+from oracle import cases, corpus_py as CP, oracle_py as O, refzlib as R
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libzref.so not built")
+
+
+def test_reference_identity():
+    assert R.version() == "1.2.3"
+    assert R.compress2(cases.HELLO, 6).hex() == "789ccb48cdc9c9d751c800518a0c0026060496"
+
+
+@pytest.mark.parametrize("level", range(0, 10))
+def test_chunk_function_matches_reference(level):
+    g = cases.Lcg(1000 + level)
+    for kind in cases.KINDS:
+        for _ in range(6):
+            n = [g.below(300), g.below(70000) % 65537, 65536 - g.below(300), 65536][g.below(4)]
+            data = cases.make(kind, n, seed=g.below(1 << 20))
+            for last in (False, True):
+                for p0 in ((False, True) if level else (False,)):
+                    assert O.deflate_chunk(data, level, last, p0) == R.deflate_chunk_raw(data, level, last, p0), (kind, n, last, p0)
+
+
+def test_stream_matches_reference_mode_b():
+    data = CP.chunks(CP.KIND_SILESIA, 40, 12).tobytes()[:-12345]
+    for lvl in (1, 6, 9):
+        z = O.deflate_stream(data, lvl)
+        assert z == R.deflate_mode_b(data, lvl)
+        rc, out = R.uncompress(z, len(data))
+        assert rc == 0 and out == data
+
+
+def test_mode_a_equals_mode_b_except_position0():
+    """in one zlib stream flushed with Z_FULL_FLUSH every 64 KiB, chunk 0 is F(.., pos0=0)
+    and every later chunk is F(.., pos0_matchable=1)."""
+    data = CP.chunks(CP.KIND_SILESIA, 0, 6).tobytes()
+    for lvl in (1, 6):
+        a = R.deflate_mode_a(data, lvl)
+        parts = [R.zlib_header(lvl)]
+        for k in range(6):
+            parts.append(O.deflate_chunk(data[k * 65536:(k + 1) * 65536], lvl, k == 5, pos0_matchable=(k > 0)))
+        parts.append(O.adler32(data).to_bytes(4, "big"))
+        assert b"".join(parts) == a
+
+
+def test_inflate_matches_reference_on_corruption():
+    g = cases.Lcg(77)
+    for kind in ("text", "rand", "runs", "mix"):
+        data = cases.make(kind, 30000, 3)
+        for lvl in (0, 1, 6, 9):
+            raw = R.deflate_chunk_raw(data, lvl, True)
+            assert O.inflate_raw(raw, len(data)) == R.inflate_raw(raw, len(data))
+            for _ in range(40):
+                c = bytearray(raw)
+                for _ in range(1 + g.below(3)):
+                    c[g.below(len(c))] ^= 1 << g.below(8)
+                a = R.inflate_raw(bytes(c), len(data) + 100)
+                b = O.inflate_raw(bytes(c), len(data) + 100)
+                assert (a[0], a[3]) == (b[0], b[3])
+                if a[0] == 1:
+                    assert a == b
+
+
+def test_checksums_match_reference():
+    import ctypes as C
+    L = R.lib()
+    L.crc32.argtypes = [C.c_ulong, C.c_char_p, C.c_uint]
+    L.crc32.restype = C.c_ulong
+    g = cases.Lcg(5)
+    for n in (0, 1, 15, 16, 17, 5551, 5552, 5553, 70000):
+        d = cases.make("rand", n, 3)
+        assert O.adler32(d) == R.adler32(d)
+        assert O.crc32(d) == L.crc32(0, d, n)
+    for _ in range(2000):
+        a, b, n = g.next() & 0xFFFFFFFF, g.next() & 0xFFFFFFFF, g.below(1 << 30)
+        a = (a & 0xFFFF) % 65521 | ((a >> 16) % 65521) << 16
+        b = (b & 0xFFFF) % 65521 | ((b >> 16) % 65521) << 16
+        assert O.adler32_combine(a, b, n) == L.adler32_combine(a, b, n)

@@ -92,11 +92,12 @@ ZC_FN void zc_word(zc_gen *g, uint32_t r, int capital)
 ZC_FN void zc_text(zc_gen *g)
 {
     uint16_t ring[64]; uint32_t nring = 0, replay = 0, rpos = 0; int cap = 1;
+    for (int i = 0; i < 64; i++) ring[i] = 0;
     while (g->pos < ZC_CHUNK) {
         uint32_t r;
         if (replay) { r = ring[rpos & 63]; rpos++; replay--; }
         else {
-            if (nring >= 16 && zc_below(g, 5) == 0) { replay = 2 + zc_below(g, 5); rpos = nring - 2 - zc_below(g, 14) - replay; }
+            if (nring >= 24 && zc_below(g, 5) == 0) { replay = 2 + zc_below(g, 5); rpos = nring - 2 - zc_below(g, 14) - replay; }
             r = zc_rank(g);
         }
         ring[nring & 63] = (uint16_t)r; nring++;
