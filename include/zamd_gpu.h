@@ -1,0 +1,145 @@
+/* zamd_gpu.h -- C ABI of the MI355X-native DEFLATE engine (libzamd_gpu.so).
+ *
+ * This is the thin HIP shim SURVEY.md section 8(b) asks for: plain pointers, sizes and int status codes,
+ * no C++ or torch types.  It sits *below* the unchanged zlib API: the zlib-compatible host library
+ * (include/zamd_zlib.h, libzamd_z.so) implements deflate()/inflate()/compress2()/uncompress() on top
+ * of the *_host entry points below, at the place where the reference dispatches to its per-level
+ * compress function and to inflate_fast:
+ *
+ *   zgpu_deflate_*   replaces  configuration_table[level].func(s, flush)   /root/reference/qcsrc/deflate.c:790
+ *                    i.e. deflate_fast / deflate_slow + longest_match      qcsrc/deflate.c:1027-1168,1448-1674
+ *                    and _tr_flush_block / compress_block                  qcsrc/trees.c:921-1016,1072-1118
+ *                    and the adler32 update inside read_buf                qcsrc/deflate.c:968-970
+ *   zgpu_inflate_*   replaces  the TYPE..LEN..CHECK states of inflate()    qcsrc/inflate.c:773-1098
+ *                    with inflate_table and inflate_fast                   qcsrc/inftrees.c:32, qcsrc/inffast.c:67
+ *
+ * Unit of work: a "chunk" = up to 65536 input bytes compressed as an independent raw-deflate segment,
+ * exactly what the reference emits for a fresh stream deflateInit2(level, 8, -15, 8, 0) fed the chunk
+ * and finished with Z_FULL_FLUSH (or Z_FINISH for the last chunk of a stream) -- "mode B" of
+ * SURVEY.md section 8(c).  Output is bit-exact with that.
+ *
+ * Status codes are zlib's (h/zlib.h:170-178) so the host library can return them unchanged.
+ */
+#ifndef ZAMD_GPU_H
+#define ZAMD_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZGPU_OK 0
+#define ZGPU_ERRNO (-1)        /* HIP runtime failure; text in zgpu_engine_error() */
+#define ZGPU_STREAM_ERROR (-2) /* bad parameters */
+#define ZGPU_DATA_ERROR (-3)   /* malformed deflate data (inflate) */
+#define ZGPU_MEM_ERROR (-4)    /* device allocation failed */
+#define ZGPU_BUF_ERROR (-5)    /* output capacity too small */
+
+#define ZGPU_CHUNK_MAX 65536u
+
+/* flags for zgpu_deflate_params.flags */
+#define ZGPU_F_FINAL 1u     /* the last chunk of this call ends the stream (BFINAL + byte align) */
+#define ZGPU_F_ZLIB_WRAP 2u /* prepend the 2-byte zlib header, append the big-endian Adler-32 (needs FINAL) */
+#define ZGPU_F_POS0 4u      /* chunks other than the first are "position-0 matchable" (mode A) */
+#define ZGPU_F_POS0_ALL 8u  /* every chunk, including the first, is position-0 matchable */
+
+/* LZ77 match-finder implementation selector (debug / A-B measurements) */
+#define ZGPU_LZ_AUTO 0
+#define ZGPU_LZ_SERIAL 1   /* one lane per chunk, tables in HBM: any level 1..9 */
+#define ZGPU_LZ_PARALLEL 2 /* static-chain search over all positions + scan parse: levels 4..9 */
+
+typedef struct zgpu_engine zgpu_engine;
+
+typedef struct {
+    int32_t level;       /* 1..9 */
+    uint32_t chunk_size; /* 1..65536; 0 selects 65536 */
+    uint32_t flags;      /* ZGPU_F_* */
+    int32_t lz_impl;     /* ZGPU_LZ_* */
+} zgpu_deflate_params;
+
+typedef struct {
+    uint64_t out_bytes;  /* bytes written to the output buffer */
+    uint64_t nchunks;
+    uint32_t adler32;    /* Adler-32 of the whole input (1 for empty input) */
+    uint32_t data_type;  /* Z_BINARY 0 / Z_TEXT 1 / Z_UNKNOWN 2, as strm->data_type after the first block */
+    uint64_t ntokens;    /* literal/match tokens over all chunks (diagnostic) */
+} zgpu_deflate_result;
+
+typedef struct {
+    uint64_t out_bytes;   /* bytes produced */
+    uint32_t adler32;     /* Adler-32 of the produced bytes */
+    int32_t first_bad_chunk; /* -1, or the first chunk that failed */
+    int32_t error_code;   /* ZGPU_OK or the failure of first_bad_chunk */
+    uint32_t error_msg;   /* index into zgpu_inflate_message() */
+} zgpu_inflate_result;
+
+/* ---- engine lifetime ---- */
+int zgpu_device_count(void);
+int zgpu_engine_create(int device, zgpu_engine **out);
+void zgpu_engine_destroy(zgpu_engine *e);
+const char *zgpu_engine_error(const zgpu_engine *e);
+const char *zgpu_version(void);
+
+/* worst-case output bytes for in_bytes of input cut into chunk_size pieces (framing included) */
+uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size);
+
+/* ---- deflate ---- */
+/* Device-resident: d_in/d_out are device pointers on the engine's device; d_chunk_offsets (optional)
+ * receives nchunks+1 byte offsets of each chunk's segment inside d_out.  hip_stream may be NULL
+ * (engine's own stream).  Blocks until the result is known. */
+int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const zgpu_deflate_params *p,
+                        void *d_out, uint64_t out_cap, uint64_t *d_chunk_offsets, zgpu_deflate_result *res,
+                        void *hip_stream);
+/* Host buffers: stages through device memory (H2D, kernels, D2H). chunk_offsets (optional, host)
+ * receives nchunks+1 offsets. */
+int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out,
+                      uint64_t out_cap, uint64_t *chunk_offsets, zgpu_deflate_result *res);
+
+/* ---- inflate ---- */
+/* Segment k = d_in[offsets[k] .. offsets[k+1]) is a raw-deflate segment that decodes to at most
+ * chunk_size bytes, written at d_out + k*chunk_size.  The last segment must end with a final block;
+ * the others end with a stored empty block (flush marker). */
+int zgpu_inflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_chunk_offsets,
+                        uint64_t nchunks, uint32_t chunk_size, void *d_out, uint64_t out_cap,
+                        zgpu_inflate_result *res, void *hip_stream);
+int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const uint64_t *chunk_offsets,
+                      uint64_t nchunks, uint32_t chunk_size, void *out, uint64_t out_cap, zgpu_inflate_result *res);
+/* Find the chunk boundaries of a mode-B stream that carries no side table: scans for the
+ * 00 00 FF FF flush markers on the device and validates the split by decoding.
+ * offsets (host, capacity max_chunks+1) receives the boundaries relative to in (raw body, no zlib
+ * header).  Returns ZGPU_OK and *nchunks, or ZGPU_DATA_ERROR when no consistent split exists. */
+int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size,
+                                  uint64_t *offsets, uint64_t max_chunks, uint64_t *nchunks);
+const char *zgpu_inflate_message(uint32_t index);
+
+/* ---- checksums (qcsrc/adler32.c:57-149) ---- */
+int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream);
+
+/* ---- measurement support ---- */
+/* Per-stage device time (HIP events on the launch stream), accumulated while profiling is on. */
+enum {
+    ZGPU_STAGE_CHAIN = 0, /* hash + static chain links */
+    ZGPU_STAGE_MATCH,     /* longest-match search */
+    ZGPU_STAGE_PARSE,     /* lazy/greedy parse -> tokens */
+    ZGPU_STAGE_LZ_SERIAL, /* serial LZ77 (levels 1-3, or forced) */
+    ZGPU_STAGE_HUFFMAN,   /* histogram + tree build + bit emit */
+    ZGPU_STAGE_STITCH,    /* size scan + concatenation + Adler-32 */
+    ZGPU_STAGE_INFLATE,
+    ZGPU_STAGE_COUNT
+};
+void zgpu_profile_enable(zgpu_engine *e, int on);
+void zgpu_profile_reset(zgpu_engine *e);
+/* total milliseconds and launch count of one stage since the last reset */
+int zgpu_profile_get(zgpu_engine *e, int stage, double *ms, uint64_t *launches);
+const char *zgpu_stage_name(int stage);
+
+/* Seeded synthetic corpora of SURVEY.md 8(d), generated in HBM (zlib_amd/csrc/corpus.h).
+ * kind 0 silesia-mix, 1 log-text; d_out receives nchunks * 65536 bytes. */
+int zgpu_corpus_fill_device(zgpu_engine *e, uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks,
+                            void *d_out, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+// zgpu_common.h -- shared device/host definitions of the MI355X DEFLATE engine.
+//
+// Constants follow /root/reference (zlib 1.2.3): h/zutil.h:81-82 (MIN/MAX_MATCH), h/deflate.h:30-48,271-276
+// (L_CODES.., MIN_LOOKAHEAD, MAX_DIST), qcsrc/deflate.c:105-110 (NIL, TOO_FAR), qcsrc/deflate.c:137-149
+// (level table), qcsrc/trees.c:61-71 (extra bits, bl_order).  The code tables of h/trees.h are
+// regenerated here at compile time from RFC 1951 instead of being copied.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zgpu {
+
+constexpr uint32_t kWSize = 32768, kWMask = kWSize - 1, kHashSize = 32768, kHashMask = kHashSize - 1;
+constexpr uint32_t kMinMatch = 3, kMaxMatch = 258, kMinLookahead = kMaxMatch + kMinMatch + 1;
+constexpr uint32_t kMaxDist = kWSize - kMinLookahead; // 32506
+constexpr uint32_t kTooFar = 4096;
+constexpr uint32_t kChunkMax = 65536;
+constexpr uint32_t kBlockTokens = 16383;       // lit_bufsize-1: a block is cut after this many tokens
+constexpr uint32_t kMaxBlocks = 6;             // ceil(65536/16383) + a possible empty final block
+constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCodes + 1, kMaxBits = 15, kMaxBLBits = 7;
+constexpr int kEndBlock = 256;
+constexpr uint32_t kSlotStride = 65536 + 256;  // per-chunk output slot (worst case: 5 stored blocks + marker = +30)
+
+struct LevelCfg { uint32_t good, lazy, nice, chain, slow; };
+inline LevelCfg level_cfg(int level)
+{
+    static const LevelCfg t[10] = {{0, 0, 0, 0, 0},      {4, 4, 8, 4, 0},      {4, 5, 16, 8, 0},      {4, 6, 32, 32, 0},
+                                   {4, 4, 16, 16, 1},    {8, 16, 32, 32, 1},   {8, 16, 128, 128, 1},  {8, 32, 128, 256, 1},
+                                   {32, 128, 258, 1024, 1}, {32, 258, 258, 4096, 1}};
+    return t[level];
+}
+
+// Per-chunk record passed between the LZ77 stage, the Huffman stage and the stitcher.
+struct ChunkMeta {
+    uint32_t ntok;        // tokens produced by the LZ77 stage
+    uint32_t nostore;     // bit b set: block b may not be emitted stored (reference: buf == NULL after the slide)
+    uint32_t out_bytes;   // compressed bytes in the chunk's slot
+    uint32_t data_type;   // Z_BINARY 0 / Z_TEXT 1 / Z_UNKNOWN 2 from the first non-empty block
+    uint32_t adler_a, adler_b; // Adler-32 halves of the chunk bytes, as if started from 1
+    uint32_t in_bytes;
+    uint32_t pad;
+};
+
+// token: bits 0..7 = literal byte or (match length - 3); bits 8..23 = match distance (0 for a literal)
+__host__ __device__ inline uint32_t tok_lit(uint32_t c) { return c; }
+__host__ __device__ inline uint32_t tok_match(uint32_t dist, uint32_t lenm3) { return lenm3 | (dist << 8); }
+
+// ---------------------------------------------------------------------------------------------------
+// RFC 1951 code tables, generated at compile time (trees.c:238-316 builds the same ones at run time).
+struct CodeTables {
+    uint8_t len_code[256];   // match length-3 -> length code 0..28
+    uint8_t dist_code[512];  // d_code() lookup, h/deflate.h:290-291
+    uint16_t base_len[29];
+    uint16_t base_dist[30];
+    uint8_t xl[29];
+    uint8_t xd[30];
+    uint16_t sl_code[288];   // static literal/length codes, bit-reversed
+    uint8_t sl_len[288];
+    uint16_t sd_code[30];
+    uint8_t bl_order[19];
+    uint8_t xbl[19];
+};
+
+constexpr unsigned bit_reverse(unsigned v, int len)
+{
+    unsigned r = 0;
+    for (int i = 0; i < len; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+}
+
+constexpr CodeTables make_code_tables()
+{
+    CodeTables t{};
+    const uint8_t xl[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    const uint8_t xd[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int i = 0; i < 29; i++) t.xl[i] = xl[i];
+    for (int i = 0; i < 30; i++) t.xd[i] = xd[i];
+    for (int i = 0; i < 19; i++) { t.bl_order[i] = order[i]; t.xbl[i] = 0; }
+    t.xbl[16] = 2; t.xbl[17] = 3; t.xbl[18] = 7;
+    int length = 0;
+    for (int code = 0; code < 28; code++) {
+        t.base_len[code] = (uint16_t)length;
+        for (int n = 0; n < (1 << xl[code]); n++) t.len_code[length++] = (uint8_t)code;
+    }
+    t.len_code[255] = 28; t.base_len[28] = 0;
+    int dist = 0, code = 0;
+    for (code = 0; code < 16; code++) {
+        t.base_dist[code] = (uint16_t)dist;
+        for (int n = 0; n < (1 << xd[code]); n++) t.dist_code[dist++] = (uint8_t)code;
+    }
+    dist >>= 7;
+    for (; code < 30; code++) {
+        t.base_dist[code] = (uint16_t)(dist << 7);
+        for (int n = 0; n < (1 << (xd[code] - 7)); n++) t.dist_code[256 + dist++] = (uint8_t)code;
+    }
+    unsigned blc[16] = {}, next[16] = {}, c = 0;
+    for (int n = 0; n < 288; n++) { t.sl_len[n] = (uint8_t)(n < 144 ? 8 : n < 256 ? 9 : n < 280 ? 7 : 8); blc[t.sl_len[n]]++; }
+    for (int n = 1; n <= 15; n++) { c = (c + blc[n - 1]) << 1; next[n] = c; }
+    for (int n = 0; n < 288; n++) t.sl_code[n] = (uint16_t)bit_reverse(next[t.sl_len[n]]++, t.sl_len[n]);
+    for (int n = 0; n < 30; n++) t.sd_code[n] = (uint16_t)bit_reverse((unsigned)n, 5);
+    return t;
+}
+
+// One copy in constant memory per translation unit that includes this header.
+__constant__ const CodeTables kTables = make_code_tables();
+
+__device__ inline uint32_t dist_code_of(uint32_t dist_minus1)
+{
+    return dist_minus1 < 256 ? kTables.dist_code[dist_minus1] : kTables.dist_code[256 + (dist_minus1 >> 7)];
+}
+
+// 3-byte hash the reference's rolling UPDATE_HASH converges to (deflate.c:170,189-192)
+__host__ __device__ inline uint32_t hash3(uint32_t b0, uint32_t b1, uint32_t b2) { return ((b0 << 10) ^ (b1 << 5) ^ b2) & kHashMask; }
+
+#define ZGPU_HIP_CHECK(expr)                                                                     \
+    do {                                                                                         \
+        hipError_t err__ = (expr);                                                               \
+        if (err__ != hipSuccess) return zgpu::fail_hip(e, err__, #expr, __FILE__, __LINE__);     \
+    } while (0)
+
+} // namespace zgpu

@@ -1,0 +1,419 @@
+// zgpu_engine.hip -- host side of the C ABI in include/zamd_gpu.h: workspace ownership, batching, kernel
+// sequencing on one HIP stream, per-stage HIP-event timing.  No torch, no C++ types cross the boundary.
+#include "zgpu_common.h"
+#include "../../include/zamd_gpu.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace zgpu {
+
+struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow; };
+
+// kernels (other translation units)
+void launch_lz_serial(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, LevelCfg cfg,
+                      uint32_t pos0_mode, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_huffman(const uint8_t *in, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, uint64_t final_chunk,
+                    const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
+void launch_adler(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, ChunkMeta *meta, hipStream_t st);
+void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
+void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
+                   uint64_t out_cap, hipStream_t st);
+void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st);
+bool lz_parallel_available();
+size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
+void launch_lz_parallel(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, LevelCfg cfg,
+                        uint32_t pos0_mode, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
+int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
+                uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
+
+} // namespace zgpu
+
+struct StageSpan { int stage; hipEvent_t a, b; };
+
+struct zgpu_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // deflate workspace, sized for `batch_cap` chunks
+    uint32_t batch_cap = 0;
+    uint32_t *tokens = nullptr;
+    zgpu::ChunkMeta *meta = nullptr;
+    uint8_t *slots = nullptr;
+    uint16_t *tables = nullptr;  // serial LZ only
+    uint32_t tables_cap = 0;
+    void *par_ws = nullptr;      // parallel LZ only
+    uint32_t par_cap = 0;
+    uint64_t *offsets = nullptr; // nchunks+1 segment offsets of the current call
+    uint64_t offsets_cap = 0;
+    void *run = nullptr;         // RunState
+    // staging for the *_host entry points
+    uint8_t *stage_in = nullptr, *stage_out = nullptr;
+    uint64_t stage_in_cap = 0, stage_out_cap = 0;
+    // inflate scratch
+    void *inf_status = nullptr; uint64_t inf_status_cap = 0;
+    // profiling
+    bool prof = false;
+    double ms[ZGPU_STAGE_COUNT] = {0};
+    uint64_t launches[ZGPU_STAGE_COUNT] = {0};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<StageSpan> spans;
+};
+
+namespace zgpu {
+
+int fail_hip(zgpu_engine *e, hipError_t err, const char *what, const char *file, int line)
+{
+    if (e) snprintf(e->err, sizeof e->err, "HIP error %d (%s) at %s:%d: %s", (int)err, hipGetErrorString(err), file, line, what);
+    if (err == hipErrorOutOfMemory) return ZGPU_MEM_ERROR;
+    return ZGPU_ERRNO;
+}
+
+static int fail(zgpu_engine *e, int code, const char *msg)
+{
+    if (e) snprintf(e->err, sizeof e->err, "%s", msg);
+    return code;
+}
+
+static hipEvent_t next_event(zgpu_engine *e)
+{
+    if (e->ev_used == e->ev_pool.size()) { hipEvent_t ev; hipEventCreate(&ev); e->ev_pool.push_back(ev); }
+    return e->ev_pool[e->ev_used++];
+}
+
+// stage timing: HIP events recorded on the launch stream around the stage's launches
+struct StageTimer {
+    zgpu_engine *e; hipStream_t st; int stage; hipEvent_t a{};
+    StageTimer(zgpu_engine *e_, hipStream_t st_, int stage_) : e(e_), st(st_), stage(stage_)
+    {
+        if (e->prof) { a = next_event(e); hipEventRecord(a, st); }
+    }
+    ~StageTimer()
+    {
+        if (e->prof) { hipEvent_t b = next_event(e); hipEventRecord(b, st); e->spans.push_back({stage, a, b}); }
+    }
+};
+
+static void collect_spans(zgpu_engine *e)
+{
+    for (auto &s : e->spans) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { e->ms[s.stage] += ms; e->launches[s.stage]++; } }
+    e->spans.clear(); e->ev_used = 0;
+}
+
+template <typename T> static int dev_alloc(zgpu_engine *e, T **p, size_t count)
+{
+    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return ZGPU_OK;
+}
+
+static uint32_t env_u32(const char *name, uint32_t dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    long x = strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
+static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64_t nchunks_total)
+{
+    int rc;
+    if (batch > e->batch_cap) {
+        hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); e->tokens = nullptr; e->meta = nullptr; e->slots = nullptr; e->batch_cap = 0;
+        if ((rc = dev_alloc(e, &e->tokens, (size_t)batch * kChunkMax))) return rc;
+        if ((rc = dev_alloc(e, &e->meta, (size_t)batch))) return rc;
+        if ((rc = dev_alloc(e, &e->slots, (size_t)batch * kSlotStride))) return rc;
+        e->batch_cap = batch;
+    }
+    if (serial && batch > e->tables_cap) {
+        hipFree(e->tables); e->tables = nullptr; e->tables_cap = 0;
+        if ((rc = dev_alloc(e, &e->tables, (size_t)batch * (kHashSize + kWSize)))) return rc;
+        e->tables_cap = batch;
+    }
+    if (!serial && batch > e->par_cap) {
+        hipFree(e->par_ws); e->par_ws = nullptr; e->par_cap = 0;
+        ZGPU_HIP_CHECK(hipMalloc(&e->par_ws, lz_parallel_workspace_bytes(batch)));
+        e->par_cap = batch;
+    }
+    if (nchunks_total + 1 > e->offsets_cap) {
+        hipFree(e->offsets); e->offsets = nullptr; e->offsets_cap = 0;
+        if ((rc = dev_alloc(e, &e->offsets, (size_t)nchunks_total + 1))) return rc;
+        e->offsets_cap = nchunks_total + 1;
+    }
+    return ZGPU_OK;
+}
+
+static void zlib_header(int level, uint8_t hdr[2]) // qcsrc/deflate.c:625-641
+{
+    unsigned h = (8u + (7u << 4)) << 8, lf = level < 2 ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
+    h |= lf << 6; h += 31 - h % 31;
+    hdr[0] = (uint8_t)(h >> 8); hdr[1] = (uint8_t)h;
+}
+
+static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, uint8_t *d_out,
+                          uint64_t out_cap, uint64_t *d_chunk_offsets, zgpu_deflate_result *res, hipStream_t st)
+{
+    if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
+    const uint32_t chunk_size = p->chunk_size ? p->chunk_size : kChunkMax;
+    if (chunk_size > kChunkMax) return fail(e, ZGPU_STREAM_ERROR, "chunk_size must be 1..65536");
+    if ((p->flags & ZGPU_F_ZLIB_WRAP) && !(p->flags & ZGPU_F_FINAL)) return fail(e, ZGPU_STREAM_ERROR, "ZLIB_WRAP needs FINAL");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    const LevelCfg cfg = level_cfg(p->level);
+    int impl = p->lz_impl;
+    if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_PARALLEL : ZGPU_LZ_SERIAL;
+    if (impl == ZGPU_LZ_PARALLEL && (!cfg.slow || !lz_parallel_available()))
+        return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
+    const bool serial = impl == ZGPU_LZ_SERIAL;
+    const uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1;
+    const uint32_t batch_max = serial ? env_u32("ZGPU_SERIAL_BATCH_CHUNKS", 65536) : env_u32("ZGPU_BATCH_CHUNKS", 8192);
+    const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
+    int rc = ensure_deflate_ws(e, batch, serial, nchunks);
+    if (rc) return rc;
+    const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP;
+    const uint64_t final_chunk = (p->flags & ZGPU_F_FINAL) ? nchunks - 1 : ~0ull;
+    const uint32_t pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
+    const uint64_t body_cap = wrap ? (out_cap >= 6 ? out_cap - 4 : 0) : out_cap;
+
+    RunStateHost rs{}; rs.out_total = wrap ? 2 : 0; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
+
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        if (serial) {
+            StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
+            ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
+            launch_lz_serial(d_in, in_bytes, chunk_size, c0, nb, cfg, pos0_mode, e->tables, e->tokens, e->meta, st);
+        } else {
+            launch_lz_parallel(d_in, in_bytes, chunk_size, c0, nb, cfg, pos0_mode, e->par_ws, e->tokens, e->meta, st, e);
+        }
+        {
+            StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
+            ZGPU_HIP_CHECK(hipMemsetAsync(e->slots, 0, (size_t)nb * kSlotStride, st));
+            launch_huffman(d_in, chunk_size, c0, nb, final_chunk, e->tokens, e->meta, e->slots, st);
+        }
+        {
+            StageTimer t(e, st, ZGPU_STAGE_STITCH);
+            launch_adler(d_in, in_bytes, chunk_size, c0, nb, e->meta, st);
+            launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st);
+            launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, st);
+        }
+        ZGPU_HIP_CHECK(hipGetLastError());
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    collect_spans(e);
+    if (rs.overflow || (wrap && out_cap < rs.out_total + 4)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
+    if (wrap) {
+        uint8_t tr[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_out + rs.out_total, tr, 4, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        rs.out_total += 4;
+    }
+    if (d_chunk_offsets) {
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_chunk_offsets, e->offsets, (nchunks + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    res->out_bytes = rs.out_total; res->nchunks = nchunks; res->adler32 = adler; res->data_type = rs.data_type; res->ntokens = rs.ntokens;
+    return ZGPU_OK;
+}
+
+static int ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes)
+{
+    if (in_bytes > e->stage_in_cap) {
+        hipFree(e->stage_in); e->stage_in = nullptr; e->stage_in_cap = 0;
+        uint64_t cap = in_bytes + (in_bytes >> 3) + 4096;
+        ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&e->stage_in), cap)); e->stage_in_cap = cap;
+    }
+    if (out_bytes > e->stage_out_cap) {
+        hipFree(e->stage_out); e->stage_out = nullptr; e->stage_out_cap = 0;
+        uint64_t cap = out_bytes + (out_bytes >> 3) + 4096;
+        ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&e->stage_out), cap)); e->stage_out_cap = cap;
+    }
+    return ZGPU_OK;
+}
+
+} // namespace zgpu
+
+using namespace zgpu;
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int zgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *zgpu_version(void) { return "zamd-gpu 0.1 (gfx950; zlib 1.2.3 bit-exact, 64 KiB independent chunks)"; }
+
+int zgpu_engine_create(int device, zgpu_engine **out)
+{
+    if (!out) return ZGPU_STREAM_ERROR;
+    *out = nullptr;
+    int n = zgpu_device_count();
+    if (device < 0 || device >= n) return ZGPU_ERRNO;
+    zgpu_engine *e = new zgpu_engine();
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&e->run, 256) != hipSuccess) {
+        delete e;
+        return ZGPU_ERRNO;
+    }
+    *out = e;
+    return ZGPU_OK;
+}
+
+void zgpu_engine_destroy(zgpu_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
+    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status);
+    for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *zgpu_engine_error(const zgpu_engine *e) { return e ? e->err : "no engine"; }
+
+uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size)
+{
+    if (chunk_size == 0 || chunk_size > kChunkMax) chunk_size = kChunkMax;
+    uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1;
+    return in_bytes + nchunks * 40 + 16; // <= 6 block headers of 5 bytes + 5-byte marker per chunk, + zlib framing
+}
+
+int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, void *d_out, uint64_t out_cap,
+                        uint64_t *d_chunk_offsets, zgpu_deflate_result *res, void *hip_stream)
+{
+    if (!e) return ZGPU_STREAM_ERROR;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, p, static_cast<uint8_t *>(d_out), out_cap, d_chunk_offsets, res, st);
+}
+
+int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out, uint64_t out_cap,
+                      uint64_t *chunk_offsets, zgpu_deflate_result *res)
+{
+    if (!e || !p || !res || (!in && in_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    const uint32_t chunk_size = p->chunk_size ? p->chunk_size : kChunkMax;
+    const uint64_t bound = zgpu_deflate_bound(in_bytes, chunk_size);
+    int rc = ensure_stage(e, in_bytes, bound);
+    if (rc) return rc;
+    if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    rc = deflate_device(e, e->stage_in, in_bytes, p, e->stage_out, bound, nullptr, res, e->stream);
+    if (rc) return rc;
+    if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (chunk_offsets) ZGPU_HIP_CHECK(hipMemcpyAsync(chunk_offsets, e->offsets, (res->nchunks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ZGPU_OK;
+}
+
+int zgpu_inflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_chunk_offsets, uint64_t nchunks,
+                        uint32_t chunk_size, void *d_out, uint64_t out_cap, zgpu_inflate_result *res, void *hip_stream)
+{
+    if (!e) return ZGPU_STREAM_ERROR;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    return inflate_run(e, static_cast<const uint8_t *>(d_in), in_bytes, d_chunk_offsets, nchunks, chunk_size, static_cast<uint8_t *>(d_out), out_cap, res, st);
+}
+
+int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const uint64_t *chunk_offsets, uint64_t nchunks, uint32_t chunk_size,
+                      void *out, uint64_t out_cap, zgpu_inflate_result *res)
+{
+    if (!e || !res || !in || !out || !chunk_offsets || nchunks == 0) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    const uint64_t need_out = nchunks * (uint64_t)chunk_size;
+    int rc = ensure_stage(e, in_bytes + 64, need_out);
+    if (rc) return rc;
+    if (nchunks + 1 > e->offsets_cap) {
+        hipFree(e->offsets); e->offsets = nullptr; e->offsets_cap = 0;
+        ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&e->offsets), (nchunks + 1) * sizeof(uint64_t))); e->offsets_cap = nchunks + 1;
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->offsets, chunk_offsets, (nchunks + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    rc = inflate_run(e, e->stage_in, in_bytes, e->offsets, nchunks, chunk_size, e->stage_out, need_out, res, e->stream);
+    if (rc) return rc;
+    if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ZGPU_OK;
+}
+
+int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream)
+{
+    if (!e || !adler_out || (!d_in && in_bytes)) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    const uint64_t nchunks = in_bytes ? (in_bytes + kChunkMax - 1) / kChunkMax : 1;
+    const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
+    int rc = ensure_deflate_ws(e, 1, false, 1);
+    if (rc) return rc;
+    ChunkMeta *meta = nullptr;
+    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&meta), (size_t)batch * sizeof(ChunkMeta)));
+    uint64_t *offs = nullptr;
+    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&offs), (nchunks + 1) * sizeof(uint64_t)));
+    RunStateHost rs{}; rs.adler_a = 1;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
+        launch_adler(static_cast<const uint8_t *>(d_in), in_bytes, kChunkMax, c0, nb, meta, st);
+        launch_scan(meta, nb, c0, offs, e->run, ~0ull, st);
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    hipFree(meta); hipFree(offs);
+    *adler_out = rs.adler_a | (rs.adler_b << 16);
+    return ZGPU_OK;
+}
+
+void zgpu_profile_enable(zgpu_engine *e, int on) { if (e) e->prof = on != 0; }
+void zgpu_profile_reset(zgpu_engine *e) { if (e) { memset(e->ms, 0, sizeof e->ms); memset(e->launches, 0, sizeof e->launches); } }
+int zgpu_profile_get(zgpu_engine *e, int stage, double *ms, uint64_t *launches)
+{
+    if (!e || stage < 0 || stage >= ZGPU_STAGE_COUNT) return ZGPU_STREAM_ERROR;
+    if (ms) *ms = e->ms[stage];
+    if (launches) *launches = e->launches[stage];
+    return ZGPU_OK;
+}
+const char *zgpu_stage_name(int stage)
+{
+    static const char *names[ZGPU_STAGE_COUNT] = {"chain", "match", "parse", "lz_serial", "huffman", "stitch", "inflate"};
+    return stage >= 0 && stage < ZGPU_STAGE_COUNT ? names[stage] : "?";
+}
+
+int zgpu_corpus_fill_device(zgpu_engine *e, uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, void *d_out, void *hip_stream)
+{
+    if (!e || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    launch_corpus(kind, seed, first_chunk, nchunks, static_cast<uint8_t *>(d_out), st);
+    ZGPU_HIP_CHECK(hipGetLastError());
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    return ZGPU_OK;
+}
+
+#pragma GCC visibility pop
+} // extern "C"
+
+// hooks used by zgpu_lz_parallel.hip to time its sub-stages with the engine's event pool
+namespace zgpu {
+void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a)
+{
+    zgpu_engine *e = static_cast<zgpu_engine *>(eng);
+    if (e && e->prof) { *a = next_event(e); hipEventRecord(*a, st); }
+}
+void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a)
+{
+    zgpu_engine *e = static_cast<zgpu_engine *>(eng);
+    if (e && e->prof) { hipEvent_t b = next_event(e); hipEventRecord(b, st); e->spans.push_back({stage, a, b}); }
+}
+} // namespace zgpu

@@ -1,0 +1,359 @@
+// zgpu_huffman.hip -- block construction stage: per-block histogram, zlib-exact Huffman trees, block-type
+// choice and bit emission, one 256-lane workgroup per chunk.
+//
+// Restates (file:line under /root/reference):
+//   init_block / tally frequencies       qcsrc/trees.c:411-424, h/deflate.h:308-324
+//   build_tree, pqdownheap, smaller      qcsrc/trees.c:434-478, 619-701   (exact heap order and depth tie-break)
+//   gen_bitlen with overflow repair      qcsrc/trees.c:490-567
+//   gen_codes / bi_reverse               qcsrc/trees.c:577-609, 1146-1156
+//   scan_tree, build_bl_tree, send_tree, send_all_trees   qcsrc/trees.c:707-862
+//   _tr_flush_block (stored / static / dynamic choice)    qcsrc/trees.c:921-1016
+//   compress_block                       qcsrc/trees.c:1072-1118
+//   _tr_stored_block, copy_block, bi_windup               qcsrc/trees.c:867-879, 1178-1219
+//   full-flush marker                    qcsrc/deflate.c:811-812
+//
+// Work split inside the workgroup: all lanes histogram the block's tokens (LDS atomics); lane 0 builds the
+// literal/length tree while lane 64 builds the distance tree (independent heaps in LDS), lane 0 then builds the
+// bit-length tree and writes the block header; all lanes then emit: every lane owns a contiguous token range,
+// sizes it, a workgroup prefix scan turns sizes into bit offsets, and each lane packs its range into 32-bit
+// words (plain stores for interior words, atomic OR for the two words it may share with a neighbour).
+#include "zgpu_common.h"
+
+namespace zgpu {
+
+constexpr int kThreads = 256;
+
+struct TreeWork {
+    uint16_t freq[kHeapSize];
+    uint16_t dad[kHeapSize];
+    uint16_t len[kHeapSize];
+    uint16_t heap[kHeapSize];
+    uint8_t depth[kHeapSize + 3];
+    uint16_t bl_count[kMaxBits + 1];
+};
+
+// LSB-first bit writer into a zero-initialised word buffer.
+struct BitWriter {
+    uint32_t *words;
+    uint32_t wi;    // index of the word being assembled
+    uint64_t acc;   // bits not yet stored (low nacc bits valid)
+    uint32_t nacc;
+    bool first;     // the word at wi may be shared with an earlier writer
+    __device__ void begin(uint32_t *base, uint64_t bitpos) { words = base; wi = (uint32_t)(bitpos >> 5); nacc = (uint32_t)(bitpos & 31); acc = 0; first = true; }
+    __device__ uint64_t pos() const { return ((uint64_t)wi << 5) + nacc; }
+    __device__ void put(uint32_t v, uint32_t nb)
+    {
+        acc |= (uint64_t)v << nacc; nacc += nb;
+        if (nacc >= 32) {
+            uint32_t w = (uint32_t)acc;
+            if (first) { atomicOr(&words[wi], w); first = false; } else words[wi] = w;
+            wi++; acc >>= 32; nacc -= 32;
+        }
+    }
+    __device__ void put64(uint64_t v, uint32_t nb)
+    {
+        if (nb > 32) { put((uint32_t)v, 32); put((uint32_t)(v >> 32), nb - 32); } else put((uint32_t)v, nb);
+    }
+    __device__ void align_byte() { uint32_t k = (8 - (nacc & 7)) & 7; if (k) put(0, k); }
+    __device__ void finish() { if (nacc) atomicOr(&words[wi], (uint32_t)acc); nacc = 0; acc = 0; }
+};
+
+__device__ inline bool lighter(const TreeWork &t, int a, int b)
+{
+    return t.freq[a] < t.freq[b] || (t.freq[a] == t.freq[b] && t.depth[a] <= t.depth[b]);
+}
+
+__device__ inline void sift_down(TreeWork &t, int heap_len, int k)
+{
+    int v = t.heap[k], j = k << 1;
+    while (j <= heap_len) {
+        if (j < heap_len && lighter(t, t.heap[j + 1], t.heap[j])) j++;
+        if (lighter(t, v, t.heap[j])) break;
+        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+    }
+    t.heap[k] = (uint16_t)v;
+}
+
+// build_tree + gen_bitlen + gen_codes, executed by one lane.  t.freq[0..elems) holds the symbol counts.
+// slen: static code lengths (constant memory) or nullptr; xbits/xbase: extra-bit table and first symbol using it.
+// Results: out_len / out_code for symbols 0..elems-1; returns max_code.  opt_len / static_len accumulate mod 2^32
+// exactly like the reference's unsigned long arithmetic does mod 2^64 (the transient "-1" of the forced codes).
+__device__ int build_tree(TreeWork &t, int elems, const uint8_t *slen, const uint8_t *xbits, int xbase, int max_length,
+                          uint16_t *out_code, uint8_t *out_len, uint32_t &opt_len, uint32_t &static_len)
+{
+    int heap_len = 0, heap_max = kHeapSize, max_code = -1, n, m, node;
+    for (n = 0; n < elems; n++) {
+        if (t.freq[n] != 0) { t.heap[++heap_len] = (uint16_t)(max_code = n); t.depth[n] = 0; }
+        else t.len[n] = 0;
+    }
+    while (heap_len < 2) {
+        node = t.heap[++heap_len] = (uint16_t)(max_code < 2 ? ++max_code : 0);
+        t.freq[node] = 1; t.depth[node] = 0; opt_len--;
+        if (slen) static_len -= slen[node];
+    }
+    for (n = heap_len / 2; n >= 1; n--) sift_down(t, heap_len, n);
+    node = elems;
+    do {
+        n = t.heap[1]; t.heap[1] = t.heap[heap_len--]; sift_down(t, heap_len, 1);
+        m = t.heap[1];
+        t.heap[--heap_max] = (uint16_t)n; t.heap[--heap_max] = (uint16_t)m;
+        t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
+        t.depth[node] = (uint8_t)((t.depth[n] >= t.depth[m] ? t.depth[n] : t.depth[m]) + 1);
+        t.dad[n] = t.dad[m] = (uint16_t)node;
+        t.heap[1] = (uint16_t)node++; sift_down(t, heap_len, 1);
+    } while (heap_len >= 2);
+    t.heap[--heap_max] = t.heap[1];
+
+    // gen_bitlen
+    int h, bits, overflow = 0;
+    for (bits = 0; bits <= kMaxBits; bits++) t.bl_count[bits] = 0;
+    t.len[t.heap[heap_max]] = 0;
+    for (h = heap_max + 1; h < kHeapSize; h++) {
+        n = t.heap[h]; bits = t.len[t.dad[n]] + 1;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        t.len[n] = (uint16_t)bits;
+        if (n > max_code) continue;
+        t.bl_count[bits]++;
+        int xb = (n >= xbase) ? xbits[n - xbase] : 0;
+        opt_len += (uint32_t)t.freq[n] * (uint32_t)(bits + xb);
+        if (slen) static_len += (uint32_t)t.freq[n] * (uint32_t)(slen[n] + xb);
+    }
+    if (overflow > 0) {
+        do {
+            bits = max_length - 1;
+            while (t.bl_count[bits] == 0) bits--;
+            t.bl_count[bits]--; t.bl_count[bits + 1] += 2; t.bl_count[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (bits = max_length; bits != 0; bits--) {
+            n = t.bl_count[bits];
+            while (n != 0) {
+                m = t.heap[--h];
+                if (m > max_code) continue;
+                if (t.len[m] != (unsigned)bits) {
+                    opt_len += ((uint32_t)bits - (uint32_t)t.len[m]) * (uint32_t)t.freq[m];
+                    t.len[m] = (uint16_t)bits;
+                }
+                n--;
+            }
+        }
+    }
+    // gen_codes
+    uint32_t next[kMaxBits + 1], c = 0;
+    for (bits = 1; bits <= kMaxBits; bits++) { c = (c + t.bl_count[bits - 1]) << 1; next[bits] = c; }
+    for (n = 0; n < elems; n++) {
+        int l = (n <= max_code) ? t.len[n] : 0;
+        out_len[n] = (uint8_t)l;
+        out_code[n] = l ? (uint16_t)(__brev(next[l]++) >> (32 - l)) : 0;
+    }
+    return max_code;
+}
+
+// scan_tree (emit == nullptr: count into blfreq) / send_tree (emit != nullptr), trees.c:707-797
+__device__ void walk_lengths(const uint8_t *len, int max_code, uint16_t *blfreq, BitWriter *emit, const uint16_t *blcode,
+                             const uint8_t *bllen)
+{
+    int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
+    if (nextlen == 0) { max_count = 138; min_count = 3; }
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = (n == max_code) ? 0xffff : len[n + 1];
+        if (++count < max_count && curlen == nextlen) continue;
+        else if (count < min_count) {
+            if (emit) { do { emit->put(blcode[curlen], bllen[curlen]); } while (--count != 0); }
+            else blfreq[curlen] += (uint16_t)count;
+        } else if (curlen != 0) {
+            if (curlen != prevlen) { if (emit) { emit->put(blcode[curlen], bllen[curlen]); count--; } else blfreq[curlen]++; }
+            if (emit) { emit->put(blcode[16], bllen[16]); emit->put((uint32_t)(count - 3), 2); } else blfreq[16]++;
+        } else if (count <= 10) {
+            if (emit) { emit->put(blcode[17], bllen[17]); emit->put((uint32_t)(count - 3), 3); } else blfreq[17]++;
+        } else {
+            if (emit) { emit->put(blcode[18], bllen[18]); emit->put((uint32_t)(count - 11), 7); } else blfreq[18]++;
+        }
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+        else { max_count = 7; min_count = 4; }
+    }
+}
+
+__device__ inline void token_bits(uint32_t t, const uint16_t *lcode, const uint8_t *llen, const uint16_t *dcode, const uint8_t *dlen,
+                                  uint64_t &bits, uint32_t &nb)
+{
+    uint32_t dist = t >> 8, lc = t & 255;
+    if (dist == 0) { bits = lcode[lc]; nb = llen[lc]; return; }
+    uint32_t c = kTables.len_code[lc], s = 257 + c;
+    bits = lcode[s]; nb = llen[s];
+    bits |= (uint64_t)(lc - kTables.base_len[c]) << nb; nb += kTables.xl[c];
+    dist--;
+    uint32_t dc = dist_code_of(dist);
+    bits |= (uint64_t)dcode[dc] << nb; nb += dlen[dc];
+    bits |= (uint64_t)(dist - kTables.base_dist[dc]) << nb; nb += kTables.xd[dc];
+}
+
+__device__ inline uint32_t block_reduce_add(uint32_t v, uint32_t *tmp)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
+// exclusive prefix sum over the 256 lanes; *total receives the sum
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint32_t *total)
+{
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= (uint32_t)o) x += y; }
+    __syncthreads();
+    if (lane == 63) tmp[wave] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += tmp[w];
+    *total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(kThreads) huffman_kernel(const uint8_t *__restrict__ in, uint32_t chunk_size, uint64_t chunk0,
+                                                           uint32_t nchunks, uint64_t final_chunk, const uint32_t *__restrict__ tokens,
+                                                           ChunkMeta *meta, uint8_t *slots)
+{
+    __shared__ TreeWork work[2];
+    __shared__ uint32_t hist[kLCodes + kDCodes + 2];
+    __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
+    __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
+    __shared__ uint32_t tmp[4];
+    __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
+    __shared__ uint64_t sh_bitpos;
+
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t gc = chunk0 + c;
+    const uint8_t *src = in + gc * chunk_size;
+    const uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    uint32_t *out = reinterpret_cast<uint32_t *>(slots + (size_t)c * kSlotStride);
+    const uint32_t ntok = meta[c].ntok, nostore = meta[c].nostore;
+    const bool final_chunk_here = (gc == final_chunk);
+    const uint32_t nblocks = ntok / kBlockTokens + 1;
+    uint32_t block_start = 0, data_type = 2;
+    if (tid == 0) sh_bitpos = 0;
+
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t t0 = b * kBlockTokens, t1 = (b + 1 == nblocks) ? ntok : t0 + kBlockTokens, nt = t1 - t0;
+        const uint32_t eof = (final_chunk_here && b + 1 == nblocks) ? 1u : 0u;
+        // ---- histogram (init_block + tally) ----
+        for (uint32_t i = tid; i < kLCodes + kDCodes + 2; i += kThreads) hist[i] = 0;
+        __syncthreads();
+        uint32_t bytes = 0;
+        for (uint32_t i = t0 + tid; i < t1; i += kThreads) {
+            uint32_t t = tok[i], dist = t >> 8, lc = t & 255;
+            if (dist == 0) { atomicAdd(&hist[lc], 1u); bytes += 1; }
+            else { atomicAdd(&hist[257 + kTables.len_code[lc]], 1u); atomicAdd(&hist[kLCodes + dist_code_of(dist - 1)], 1u); bytes += lc + 3; }
+        }
+        const uint32_t stored_len = block_reduce_add(bytes, tmp);
+        __syncthreads();
+        if (tid == 0) hist[kEndBlock] = 1;
+        __syncthreads();
+        if (b == 0 && stored_len > 0) { // set_data_type, trees.c:1126-1139 (first block of the stream decides)
+            bool bin = false;
+            if (tid < 32 && (tid < 9 || tid >= 14)) bin = hist[tid] != 0;
+            data_type = __syncthreads_or(bin) ? 0u : 1u;
+        }
+        for (uint32_t i = tid; i < kLCodes; i += kThreads) work[0].freq[i] = (uint16_t)hist[i];
+        if (tid < kDCodes) work[1].freq[tid] = (uint16_t)hist[kLCodes + tid];
+        __syncthreads();
+        // ---- trees ----
+        if (tid == 0) {
+            uint32_t o = 0, s = 0;
+            sh_lmax = (uint32_t)build_tree(work[0], kLCodes, kTables.sl_len, kTables.xl, 257, kMaxBits, lcode, llen, o, s);
+            sh_optl = o; sh_statl = s;
+        } else if (tid == 64) {
+            __shared__ uint8_t five[kDCodes];
+            for (int i = 0; i < kDCodes; i++) five[i] = 5;
+            uint32_t o = 0, s = 0;
+            sh_dmax = (uint32_t)build_tree(work[1], kDCodes, five, kTables.xd, 0, kMaxBits, dcode, dlen, o, s);
+            sh_optd = o; sh_statd = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t opt_len = sh_optl + sh_optd, static_len = sh_statl + sh_statd;
+            const int lmax = (int)sh_lmax, dmax = (int)sh_dmax;
+            TreeWork &w = work[0];
+            for (int i = 0; i < kBLCodes; i++) w.freq[i] = 0;
+            walk_lengths(llen, lmax, w.freq, nullptr, nullptr, nullptr);
+            walk_lengths(dlen, dmax, w.freq, nullptr, nullptr, nullptr);
+            uint32_t dummy = 0;
+            build_tree(w, kBLCodes, nullptr, kTables.xbl, 0, kMaxBLBits, blcode, bllen, opt_len, dummy);
+            int max_blindex;
+            for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--) if (bllen[kTables.bl_order[max_blindex]] != 0) break;
+            opt_len += 3 * (uint32_t)(max_blindex + 1) + 5 + 5 + 4;
+            uint32_t opt_lenb = (opt_len + 3 + 7) >> 3, static_lenb = (static_len + 3 + 7) >> 3;
+            if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+            uint32_t btype;
+            if (stored_len + 4 <= opt_lenb && !((nostore >> b) & 1)) btype = 0;
+            else if (static_lenb == opt_lenb) btype = 1;
+            else btype = 2;
+            sh_btype = btype;
+            // ---- block header ----
+            BitWriter bw; bw.begin(out, sh_bitpos);
+            bw.put((btype << 1) + eof, 3);
+            if (btype == 0) {
+                bw.align_byte(); bw.put(stored_len & 0xffff, 16); bw.put(~stored_len & 0xffff, 16);
+            } else if (btype == 2) {
+                bw.put((uint32_t)(lmax + 1 - 257), 5); bw.put((uint32_t)(dmax + 1 - 1), 5); bw.put((uint32_t)(max_blindex + 1 - 4), 4);
+                for (int r = 0; r <= max_blindex; r++) bw.put(bllen[kTables.bl_order[r]], 3);
+                walk_lengths(llen, lmax, nullptr, &bw, blcode, bllen);
+                walk_lengths(dlen, dmax, nullptr, &bw, blcode, bllen);
+            }
+            sh_bitpos = bw.pos();
+            bw.finish();
+        }
+        __syncthreads();
+        const uint32_t btype = sh_btype;
+        uint64_t bitpos = sh_bitpos;
+        if (btype == 0) {
+            uint8_t *dst = reinterpret_cast<uint8_t *>(out) + (bitpos >> 3);
+            for (uint32_t i = tid; i < stored_len; i += kThreads) dst[i] = src[block_start + i];
+            bitpos += (uint64_t)stored_len * 8;
+        } else {
+            if (btype == 1) { // static trees: load the fixed codes into the same LDS tables
+                for (uint32_t i = tid; i < kLCodes; i += kThreads) { lcode[i] = kTables.sl_code[i]; llen[i] = kTables.sl_len[i]; }
+                if (tid < kDCodes) { dcode[tid] = kTables.sd_code[tid]; dlen[tid] = 5; }
+                __syncthreads();
+            }
+            // every lane owns a contiguous run of tokens
+            const uint32_t per = (nt + kThreads - 1) / kThreads;
+            const uint32_t a = t0 + (tid * per < nt ? tid * per : nt), z = t0 + ((tid + 1) * per < nt ? (tid + 1) * per : nt);
+            uint32_t mybits = 0;
+            for (uint32_t i = a; i < z; i++) { uint64_t v; uint32_t nb; token_bits(tok[i], lcode, llen, dcode, dlen, v, nb); mybits += nb; }
+            if (tid == kThreads - 1) mybits += llen[kEndBlock];
+            uint32_t total, off = block_exclusive_scan(mybits, tmp, &total);
+            BitWriter bw; bw.begin(out, bitpos + off);
+            for (uint32_t i = a; i < z; i++) { uint64_t v; uint32_t nb; token_bits(tok[i], lcode, llen, dcode, dlen, v, nb); bw.put64(v, nb); }
+            if (tid == kThreads - 1) bw.put(lcode[kEndBlock], llen[kEndBlock]);
+            bw.finish();
+            bitpos += total;
+        }
+        block_start += stored_len;
+        __syncthreads();
+        if (tid == 0) sh_bitpos = bitpos;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        BitWriter bw; bw.begin(out, sh_bitpos);
+        if (!final_chunk_here) { bw.put(0, 3); bw.align_byte(); bw.put(0, 16); bw.put(0xffff, 16); } // flush marker
+        else bw.align_byte();                                                                        // bi_windup
+        uint64_t endpos = bw.pos();
+        bw.finish();
+        meta[c].out_bytes = (uint32_t)(endpos >> 3);
+        meta[c].data_type = data_type;
+    }
+}
+
+void launch_huffman(const uint8_t *in, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, uint64_t final_chunk,
+                    const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st)
+{
+    hipLaunchKernelGGL(huffman_kernel, dim3(nchunks), dim3(kThreads), 0, st, in, chunk_size, chunk0, nchunks, final_chunk, tokens, meta,
+                       slots);
+}
+
+} // namespace zgpu

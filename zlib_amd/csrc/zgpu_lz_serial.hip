@@ -1,0 +1,151 @@
+// zgpu_lz_serial.hip -- LZ77 stage, serial form: one lane per chunk, hash tables in HBM.
+//
+// This is the reference's deflate_fast (levels 1-3) / deflate_slow (levels 4-9) control flow
+// (/root/reference/qcsrc/deflate.c:1448-1546, 1554-1674) with longest_match (deflate.c:1027-1168),
+// expressed on chunk offsets.  It is the only LZ77 form for levels 1-3, whose hash chains depend on
+// the parse (insertions are skipped after long matches, deflate.c:1510-1534), and the cross-check
+// form for levels 4-9 (zgpu_lz_parallel.hip is the fast one there).
+//
+// Window bookkeeping without moving memory.  The reference keeps 16-bit window indices in head[]/prev[]
+// and rebases all of them when it slides the window (deflate.c:1293-1326).  A chunk is at most 64 KiB, so
+// at most one slide happens, late (window index >= 65274).  Here tables hold p+1 (p = chunk offset, 0 =
+// never inserted) and the window index is derived on the fly: w = p + base - off, base = 3 for a
+// position-0-matchable chunk, off = 32768 once the slide has happened.  An entry is the
+// reference's NIL exactly when its derived index is <= 0.
+#include "zgpu_common.h"
+
+namespace zgpu {
+
+struct SerialLz {
+    const uint8_t *__restrict__ in;
+    uint32_t n, base, off;
+    uint16_t *head, *prev;
+    uint32_t *tok;
+    uint32_t ntok, blk_tok0, nblk, nostore, block_start;
+    LevelCfg cfg;
+
+    __device__ int widx(uint32_t p) const { return (int)(p + base) - (int)off; }
+    // derived window index of a table entry; <= 0 means NIL
+    __device__ int entry_w(uint32_t e) const { return e == 0 ? 0 : (int)(e - 1 + base) - (int)off; }
+
+    __device__ uint32_t insert(uint32_t p)
+    {
+        uint32_t h = hash3(in[p], in[p + 1], in[p + 2]);
+        uint32_t old = head[h];
+        prev[(p + base) & kWMask] = (uint16_t)old;
+        head[h] = (uint16_t)(p + 1);
+        return old;
+    }
+
+    // the slide test of fill_window (deflate.c:1293); called wherever the reference calls fill_window
+    __device__ void refill(uint32_t p) { if (widx(p) >= (int)(kWSize + kMaxDist)) off += kWSize; }
+
+    __device__ void cut_block(uint32_t p_end)
+    {
+        if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // buf == NULL, deflate.c:1365-1367
+        nblk++; blk_tok0 = ntok; block_start = p_end;
+    }
+    __device__ bool emit(uint32_t t) { tok[ntok++] = t; return ntok - blk_tok0 == kBlockTokens; }
+
+    // longest_match; e0 is the table entry of the first candidate.  Returns the match length and sets mstart.
+    __device__ uint32_t longest(uint32_t p, uint32_t e0, uint32_t prev_length, uint32_t &mstart) const
+    {
+        uint32_t chain = cfg.chain, look = n - p, nice = cfg.nice, best = prev_length;
+        int w = widx(p), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+        uint32_t cap = look < kMaxMatch ? look : kMaxMatch;
+        if (prev_length >= cfg.good) chain >>= 2;
+        if (nice > look) nice = look;
+        uint32_t e = e0;
+        const uint8_t *scan = in + p;
+        do {
+            uint32_t q = e - 1;
+            const uint8_t *m = in + q;
+            // quick reject on the byte that would extend the best match so far (deflate.c:1121-1124)
+            if (best < cap ? (m[best] == scan[best]) : false) {
+                uint32_t l = 0;
+                while (l < cap && m[l] == scan[l]) l++;
+                if (l > best) { mstart = q; best = l; if (l >= nice) break; }
+            }
+            e = prev[(q + base) & kWMask];
+            if (e == 0 || entry_w(e) <= limit) break;
+        } while (--chain != 0);
+        return best <= look ? best : look;
+    }
+};
+
+template <bool kSlow>
+__device__ void lz_serial_chunk(SerialLz &s)
+{
+    const uint32_t n = s.n;
+    uint32_t room = 2 * kWSize - s.base, buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
+    uint32_t p = 0, match_len = kMinMatch - 1, prev_len = 0, mstart = 0, prev_match = 0, hh = 0;
+    bool pending = false;
+    for (;;) {
+        if (buffered - p < kMinLookahead) { s.refill(p); buffered = n; if (n == p) break; }
+        uint32_t look = n - p;
+        if (look >= kMinMatch) hh = s.insert(p);
+        int hw = s.entry_w(hh), w = s.widx(p);
+        bool cut = false;
+        if (kSlow) {
+            prev_len = match_len; prev_match = mstart; match_len = kMinMatch - 1;
+            if (hw > 0 && prev_len < s.cfg.lazy && (uint32_t)(w - hw) <= kMaxDist) {
+                match_len = s.longest(p, hh, prev_len, mstart);
+                if (match_len == kMinMatch && p - mstart > kTooFar) match_len = kMinMatch - 1;
+            }
+            if (prev_len >= kMinMatch && match_len <= prev_len) {
+                uint32_t max_insert = p + look - kMinMatch, k = prev_len - 2;
+                cut = s.emit(tok_match(p - 1 - prev_match, prev_len - kMinMatch));
+                do { if (++p <= max_insert) hh = s.insert(p); } while (--k != 0);
+                pending = false; match_len = kMinMatch - 1; p++;
+                if (cut) s.cut_block(p);
+            } else if (pending) {
+                cut = s.emit(tok_lit(s.in[p - 1]));
+                if (cut) s.cut_block(p);
+                p++;
+            } else { pending = true; p++; }
+        } else {
+            if (hw > 0 && (uint32_t)(w - hw) <= kMaxDist) match_len = s.longest(p, hh, kMinMatch - 1, mstart);
+            if (match_len >= kMinMatch) {
+                cut = s.emit(tok_match(p - mstart, match_len - kMinMatch));
+                look -= match_len;
+                if (match_len <= s.cfg.lazy && look >= kMinMatch) { // cfg.lazy is max_insert_length here (h/deflate.h:176)
+                    match_len--;
+                    do { p++; hh = s.insert(p); } while (--match_len != 0);
+                    p++;
+                } else { p += match_len; match_len = 0; }
+            } else { cut = s.emit(tok_lit(s.in[p])); p++; }
+            if (cut) s.cut_block(p);
+        }
+    }
+    if (kSlow && pending) s.emit(tok_lit(s.in[p - 1]));
+    s.cut_block(p); // the final block (its emission happens in the Huffman stage)
+}
+
+// grid: one lane per chunk of the batch.  tables: per chunk 2 x 32768 u16 (head zeroed by the host side).
+__global__ void __launch_bounds__(64) lz_serial_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint32_t chunk_size,
+                                                       uint64_t chunk0, uint32_t nchunks, LevelCfg cfg, uint32_t pos0_mode,
+                                                       uint16_t *tables, uint32_t *tokens, ChunkMeta *meta)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    uint64_t gc = chunk0 + c, lo = gc * chunk_size;
+    uint64_t rem = in_bytes - lo;
+    SerialLz s;
+    s.in = in + lo; s.n = (uint32_t)(rem < chunk_size ? rem : chunk_size);
+    s.base = (pos0_mode == 2 || (pos0_mode == 1 && gc != 0)) ? 3u : 0u; s.off = 0;
+    s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
+    s.tok = tokens + (size_t)c * kChunkMax;
+    s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = 0; s.cfg = cfg;
+    if (cfg.slow) lz_serial_chunk<true>(s); else lz_serial_chunk<false>(s);
+    meta[c].ntok = s.ntok; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
+}
+
+void launch_lz_serial(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks,
+                      LevelCfg cfg, uint32_t pos0_mode, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    dim3 grid((nchunks + 63) / 64), block(64);
+    hipLaunchKernelGGL(lz_serial_kernel, grid, block, 0, st, in, in_bytes, chunk_size, chunk0, nchunks, cfg, pos0_mode, tables,
+                       tokens, meta);
+}
+
+} // namespace zgpu

@@ -1,0 +1,154 @@
+// zgpu_stitch.hip -- everything between per-chunk segments and one stream: Adler-32 per chunk
+// (/root/reference/qcsrc/adler32.c:57-125 as a parallel reduction), ordered combination of the chunk checksums
+// (adler32.c:128-149 as an associative monoid), exclusive scan of segment sizes, and the copy of every
+// segment to its final byte offset ("stitching").  Segments end byte-aligned (flush marker / bi_windup), so
+// stitching is a byte copy, never a bit shift.  Also hosts the corpus generator kernel used by bench.py.
+#include "zgpu_common.h"
+#include "corpus.h"
+
+namespace zgpu {
+
+constexpr uint32_t kAdlerBase = 65521;
+
+// running totals carried across batches of one call (device memory)
+struct RunState {
+    uint64_t out_total; // bytes placed so far (starts at 2 when a zlib header is prepended)
+    uint64_t in_total;
+    uint64_t ntokens;
+    uint32_t adler_a, adler_b; // Adler-32 halves of all input so far (a starts at 1, b at 0)
+    uint32_t data_type;
+    uint32_t overflow;         // set when the output capacity was exceeded
+};
+
+// ---- Adler-32 of each chunk: A = 1 + sum b_i, B = n + sum (n - i) b_i (mod 65521) ----
+__global__ void __launch_bounds__(256) adler_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0,
+                                                    uint32_t nchunks, ChunkMeta *meta)
+{
+    __shared__ uint64_t red2[4];
+    __shared__ uint32_t red1[4];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t lo = (chunk0 + c) * (uint64_t)chunk_size, rem = in_bytes - lo;
+    const uint32_t n = (uint32_t)(rem < chunk_size ? rem : chunk_size);
+    const uint8_t *src = in + lo;
+    uint32_t s1 = 0; uint64_t s2 = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *v = reinterpret_cast<const uint4 *>(src);
+        const uint32_t nvec = n >> 4;
+        for (uint32_t i = tid; i < nvec; i += 256) {
+            uint4 q = v[i];
+            uint32_t w[4] = {q.x, q.y, q.z, q.w}, o = i << 4, t1 = 0, t2 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { uint32_t b = (w[k] >> (8 * j)) & 255; t1 += b; t2 += b * (uint32_t)(k * 4 + j); }
+            }
+            s1 += t1; s2 += (uint64_t)(n - o) * t1 - t2;
+        }
+        for (uint32_t i = (nvec << 4) + tid; i < n; i += 256) { uint32_t b = src[i]; s1 += b; s2 += (uint64_t)(n - i) * b; }
+    } else {
+        for (uint32_t i = tid; i < n; i += 256) { uint32_t b = src[i]; s1 += b; s2 += (uint64_t)(n - i) * b; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+    if ((tid & 63) == 0) { red1[tid >> 6] = s1; red2[tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t a = 1 + (uint64_t)red1[0] + red1[1] + red1[2] + red1[3];
+        uint64_t b = n + red2[0] % kAdlerBase + red2[1] % kAdlerBase + red2[2] % kAdlerBase + red2[3] % kAdlerBase;
+        meta[c].adler_a = (uint32_t)(a % kAdlerBase); meta[c].adler_b = (uint32_t)(b % kAdlerBase); meta[c].in_bytes = n;
+    }
+}
+
+// Adler of X||Y from Adler(X) = (ax, bx), Adler(Y) = (ay, by), |Y| = ny:  a = ax + ay - 1,  b = bx + by + ny (ax - 1)
+__device__ inline void adler_join(uint32_t &ax, uint32_t &bx, uint32_t ay, uint32_t by, uint64_t ny)
+{
+    uint64_t rem = ny % kAdlerBase;
+    uint64_t a = ((uint64_t)ax + ay + kAdlerBase - 1) % kAdlerBase;
+    uint64_t b = ((uint64_t)bx + by + rem * ((ax + kAdlerBase - 1) % kAdlerBase)) % kAdlerBase;
+    ax = (uint32_t)a; bx = (uint32_t)b;
+}
+
+// One workgroup: exclusive scan of out_bytes over the batch (continuing RunState), ordered Adler combination.
+__global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict__ meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets,
+                                                    RunState *run, uint64_t out_cap)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t pa[1024], pb[1024];
+    __shared__ uint64_t plen[1024], ptok[1024];
+    const uint32_t tid = threadIdx.x, per = (nchunks + 1023) / 1024;
+    const uint32_t a = tid * per < nchunks ? tid * per : nchunks, z = (tid + 1) * per < nchunks ? (tid + 1) * per : nchunks;
+    uint64_t sum = 0, len = 0, ntok = 0; uint32_t xa = 1, xb = 0;
+    for (uint32_t i = a; i < z; i++) {
+        sum += meta[i].out_bytes; ntok += meta[i].ntok;
+        adler_join(xa, xb, meta[i].adler_a, meta[i].adler_b, meta[i].in_bytes); len += meta[i].in_bytes;
+    }
+    part[tid] = sum; pa[tid] = xa; pb[tid] = xb; plen[tid] = len; ptok[tid] = ntok;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t acc = run->out_total, tl = 0, tt = 0; uint32_t ra = run->adler_a, rb = run->adler_b;
+        for (uint32_t t = 0; t < 1024; t++) {
+            uint64_t s = part[t]; part[t] = acc; acc += s;
+            adler_join(ra, rb, pa[t], pb[t], plen[t]); tl += plen[t]; tt += ptok[t];
+        }
+        run->out_total = acc; run->adler_a = ra; run->adler_b = rb; run->in_total += tl; run->ntokens += tt;
+        if (chunk0 == 0 && nchunks > 0) run->data_type = meta[0].data_type;
+        if (acc > out_cap) run->overflow = 1;
+        offsets[chunk0 + nchunks] = acc;
+    }
+    __syncthreads();
+    uint64_t o = part[tid];
+    for (uint32_t i = a; i < z; i++) { offsets[chunk0 + i] = o; o += meta[i].out_bytes; }
+}
+
+// copy slot c to out + offsets[chunk0 + c]; 4-byte destination-aligned stores
+__global__ void __launch_bounds__(256) stitch_kernel(const uint8_t *__restrict__ slots, const ChunkMeta *__restrict__ meta,
+                                                     const uint64_t *__restrict__ offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
+                                                     uint64_t out_cap)
+{
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    if (c >= nchunks) return;
+    const uint32_t n = meta[c].out_bytes;
+    const uint64_t off = offsets[chunk0 + c];
+    if (off + n > out_cap) return; // reported through RunState.overflow
+    const uint8_t *src = slots + (size_t)c * kSlotStride;
+    uint8_t *dst = out + off;
+    uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+    if (head > n) head = n;
+    if (tid < head) dst[tid] = src[tid];
+    const uint32_t nwords = (n - head) >> 2;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+    const uint32_t sh = head & 3, w0 = head >> 2;
+    for (uint32_t j = tid; j < nwords; j += 256) {
+        uint32_t lo = s32[w0 + j], hi = s32[w0 + j + 1]; // slot has slack, reading one word past is in bounds
+        d32[j] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    }
+    const uint32_t done = head + (nwords << 2);
+    if (tid < n - done) dst[done + tid] = src[done + tid];
+}
+
+__global__ void __launch_bounds__(64) corpus_kernel(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nchunks) zc_fill_chunk(kind, seed, first_chunk + i, out + i * ZC_CHUNK);
+}
+
+void launch_adler(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, ChunkMeta *meta, hipStream_t st)
+{
+    hipLaunchKernelGGL(adler_kernel, dim3(nchunks), dim3(256), 0, st, in, in_bytes, chunk_size, chunk0, nchunks, meta);
+}
+void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, meta, nchunks, chunk0, offsets, static_cast<RunState *>(run), out_cap);
+}
+void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
+                   uint64_t out_cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(stitch_kernel, dim3(nchunks), dim3(256), 0, st, slots, meta, offsets, chunk0, nchunks, out, out_cap);
+}
+void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(corpus_kernel, dim3((uint32_t)((nchunks + 63) / 64)), dim3(64), 0, st, kind, seed, first_chunk, nchunks, out);
+}
+
+} // namespace zgpu

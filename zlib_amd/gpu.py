@@ -1,0 +1,184 @@
+"""ctypes binding of libzamd_gpu.so (C ABI: include/zamd_gpu.h).  Plumbing only."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL = 1, 2, 4, 8
+LZ_AUTO, LZ_SERIAL, LZ_PARALLEL = 0, 1, 2
+STAGES = ["chain", "match", "parse", "lz_serial", "huffman", "stitch", "inflate"]
+CHUNK = 65536
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("zgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("level", C.c_int32), ("chunk_size", C.c_uint32), ("flags", C.c_uint32), ("lz_impl", C.c_int32)]
+
+
+class DeflateResult(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("nchunks", C.c_uint64), ("adler32", C.c_uint32), ("data_type", C.c_uint32),
+                ("ntokens", C.c_uint64)]
+
+
+class InflateResult(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("adler32", C.c_uint32), ("first_bad_chunk", C.c_int32),
+                ("error_code", C.c_int32), ("error_msg", C.c_uint32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libzamd_gpu.so")
+
+
+def load_library():
+    """Load the HIP engine.  Fails loudly when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: build it with `make -C zlib_amd/csrc` (or __graft_entry__.build())" % path)
+    L = C.CDLL(path)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.zgpu_device_count.restype = C.c_int
+    L.zgpu_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.zgpu_engine_destroy.argtypes = [vp]
+    L.zgpu_engine_destroy.restype = None
+    L.zgpu_engine_error.argtypes = [vp]
+    L.zgpu_engine_error.restype = C.c_char_p
+    L.zgpu_version.restype = C.c_char_p
+    L.zgpu_deflate_bound.argtypes = [u64, u32]
+    L.zgpu_deflate_bound.restype = u64
+    L.zgpu_deflate_device.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
+    L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
+    L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
+    L.zgpu_inflate_host.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
+    L.zgpu_inflate_find_chunks_host.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64)]
+    L.zgpu_inflate_message.argtypes = [u32]
+    L.zgpu_inflate_message.restype = C.c_char_p
+    L.zgpu_adler32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
+    L.zgpu_profile_enable.argtypes = [vp, C.c_int]
+    L.zgpu_profile_enable.restype = None
+    L.zgpu_profile_reset.argtypes = [vp]
+    L.zgpu_profile_reset.restype = None
+    L.zgpu_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.zgpu_stage_name.argtypes = [C.c_int]
+    L.zgpu_stage_name.restype = C.c_char_p
+    L.zgpu_corpus_fill_device.argtypes = [vp, u32, u64, u64, u64, vp, vp]
+    _lib = L
+    return L
+
+
+class Engine:
+    """One engine per process and GPU (one process per GPU is the deployment model)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.zgpu_engine_create(device, C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, "cannot create engine on device %d (%d visible)" % (device, self.L.zgpu_device_count()))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.zgpu_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.zgpu_engine_error(self.h).decode())
+
+    # ---- deflate ----
+    def deflate_host(self, data, level, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO, want_offsets=False):
+        """data: bytes-like or numpy uint8 array.  Returns bytes (and the chunk offsets when asked)."""
+        import numpy as np
+        arr = np.frombuffer(data, dtype=np.uint8) if not hasattr(data, "ctypes") else data
+        n = int(arr.size)
+        cap = self.L.zgpu_deflate_bound(n, chunk_size)
+        out = np.empty(cap, dtype=np.uint8)
+        nchunks = max(1, (n + chunk_size - 1) // chunk_size)
+        offs = np.zeros(nchunks + 1, dtype=np.uint64)
+        p = _Params(level, chunk_size, flags, lz_impl)
+        res = DeflateResult()
+        src = arr.ctypes.data if n else None
+        self._check(self.L.zgpu_deflate_host(self.h, src, n, C.byref(p), out.ctypes.data, cap,
+                                             offs.ctypes.data if want_offsets else None, C.byref(res)))
+        self.last = res
+        z = out[: res.out_bytes].tobytes()
+        return (z, offs) if want_offsets else z
+
+    def deflate_device(self, d_in, n, level, d_out, out_cap, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO,
+                       d_offsets=None, stream=None):
+        """d_in / d_out / d_offsets: device pointers as ints (e.g. torch.Tensor.data_ptr())."""
+        p = _Params(level, chunk_size, flags, lz_impl)
+        res = DeflateResult()
+        self._check(self.L.zgpu_deflate_device(self.h, d_in, n, C.byref(p), d_out, out_cap, d_offsets, C.byref(res), stream))
+        return res
+
+    # ---- inflate ----
+    def inflate_host(self, data, offsets, chunk_size=CHUNK, out_len=None):
+        import numpy as np
+        arr = np.frombuffer(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nchunks = len(offs) - 1
+        cap = nchunks * chunk_size if out_len is None else out_len
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        res = InflateResult()
+        rc = self.L.zgpu_inflate_host(self.h, arr.ctypes.data, arr.size, offs.ctypes.data, nchunks, chunk_size, out.ctypes.data, cap,
+                                      C.byref(res))
+        self.last_inflate = res
+        if rc != 0:
+            msg = self.L.zgpu_inflate_message(res.error_msg).decode() if rc == -3 else self.L.zgpu_engine_error(self.h).decode()
+            raise EngineError(rc, msg)
+        return out[: res.out_bytes].tobytes()
+
+    def inflate_device(self, d_in, n, d_offsets, nchunks, d_out, out_cap, chunk_size=CHUNK, stream=None):
+        res = InflateResult()
+        rc = self.L.zgpu_inflate_device(self.h, d_in, n, d_offsets, nchunks, chunk_size, d_out, out_cap, C.byref(res), stream)
+        if rc != 0:
+            msg = self.L.zgpu_inflate_message(res.error_msg).decode() if rc == -3 else self.L.zgpu_engine_error(self.h).decode()
+            raise EngineError(rc, msg)
+        return res
+
+    def find_chunks_host(self, body, chunk_size=CHUNK, max_chunks=None):
+        import numpy as np
+        arr = np.frombuffer(body, dtype=np.uint8)
+        max_chunks = max_chunks or (arr.size // 5 + 2)
+        offs = np.zeros(max_chunks + 1, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.L.zgpu_inflate_find_chunks_host(self.h, arr.ctypes.data, arr.size, chunk_size, offs.ctypes.data, max_chunks,
+                                                         C.byref(n)))
+        return offs[: n.value + 1]
+
+    # ---- misc ----
+    def adler32_device(self, d_in, n, stream=None):
+        a = C.c_uint32(0)
+        self._check(self.L.zgpu_adler32_device(self.h, d_in, n, C.byref(a), stream))
+        return a.value
+
+    def corpus_fill_device(self, kind, seed, first_chunk, nchunks, d_out, stream=None):
+        self._check(self.L.zgpu_corpus_fill_device(self.h, kind, seed, first_chunk, nchunks, d_out, stream))
+
+    def profile(self, on=True):
+        self.L.zgpu_profile_enable(self.h, int(on))
+        self.L.zgpu_profile_reset(self.h)
+
+    def profile_read(self):
+        out = {}
+        for i, name in enumerate(STAGES):
+            ms, n = C.c_double(0), C.c_uint64(0)
+            self.L.zgpu_profile_get(self.h, i, C.byref(ms), C.byref(n))
+            out[name] = (ms.value, n.value)
+        return out
