@@ -96,6 +96,17 @@ int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, con
 int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out,
                       uint64_t out_cap, uint64_t *chunk_offsets, zgpu_deflate_result *res);
 
+/* Batch of independent small buffers: segment k = in[seg_offsets[k] .. seg_offsets[k+1]), each at most
+ * 65536 bytes, becomes one chunk.  With ZGPU_F_FINAL every segment is a complete raw-deflate stream of its
+ * own (Z_FINISH); without it every segment ends with the full-flush marker.  ZGPU_F_POS0_ALL applies to all
+ * segments; ZGPU_F_ZLIB_WRAP is not allowed.  out_offsets (optional) receives nseg+1 output offsets. */
+int zgpu_deflate_segments_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_seg_offsets,
+                                 uint64_t nseg, const zgpu_deflate_params *p, void *d_out, uint64_t out_cap,
+                                 uint64_t *d_out_offsets, zgpu_deflate_result *res, void *hip_stream);
+int zgpu_deflate_segments_host(zgpu_engine *e, const void *in, const uint64_t *seg_offsets, uint64_t nseg,
+                               const zgpu_deflate_params *p, void *out, uint64_t out_cap, uint64_t *out_offsets,
+                               zgpu_deflate_result *res);
+
 /* ---- inflate ---- */
 /* Segment k = d_in[offsets[k] .. offsets[k+1]) is a raw-deflate segment that decodes to at most
  * chunk_size bytes, written at d_out + k*chunk_size.  The last segment must end with a final block;

@@ -41,6 +41,28 @@ struct ChunkMeta {
     uint32_t pad;
 };
 
+// Where the chunks of one launch live.  Either uniform (chunk k = bytes [k*chunk_size, ...)) or an explicit
+// segment table (chunk k = bytes [seg_off[k], seg_off[k+1])), each segment at most 65536 bytes.
+struct ChunkGeom {
+    const uint8_t *in;
+    uint64_t in_bytes;
+    const uint64_t *seg_off; // nullptr: uniform chunking
+    uint64_t chunk0;         // global index of the first chunk of this batch
+    uint64_t final_chunk;    // global index of the chunk that carries BFINAL (~0: none)
+    uint32_t chunk_size;
+    uint32_t nchunks;        // chunks in this batch
+    uint32_t all_final;      // every chunk is a complete stream of its own
+    uint32_t pos0_mode;      // 0 none, 1 chunks other than global chunk 0, 2 all chunks are position-0 matchable
+};
+__device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, uint32_t &n)
+{
+    const uint64_t gc = g.chunk0 + c;
+    if (g.seg_off) { lo = g.seg_off[gc]; n = (uint32_t)(g.seg_off[gc + 1] - lo); }
+    else { lo = gc * g.chunk_size; uint64_t rem = g.in_bytes - lo; n = (uint32_t)(rem < g.chunk_size ? rem : g.chunk_size); }
+}
+__device__ inline bool chunk_is_final(const ChunkGeom &g, uint32_t c) { return g.all_final || g.chunk0 + c == g.final_chunk; }
+__device__ inline uint32_t chunk_base(const ChunkGeom &g, uint32_t c) { return (g.pos0_mode == 2 || (g.pos0_mode == 1 && g.chunk0 + c != 0)) ? 3u : 0u; }
+
 // token: bits 0..7 = literal byte or (match length - 3); bits 8..23 = match distance (0 for a literal)
 __host__ __device__ inline uint32_t tok_lit(uint32_t c) { return c; }
 __host__ __device__ inline uint32_t tok_match(uint32_t dist, uint32_t lenm3) { return lenm3 | (dist << 8); }

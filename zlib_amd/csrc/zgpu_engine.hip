@@ -12,19 +12,16 @@ namespace zgpu {
 struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow; };
 
 // kernels (other translation units)
-void launch_lz_serial(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, LevelCfg cfg,
-                      uint32_t pos0_mode, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
-void launch_huffman(const uint8_t *in, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, uint64_t final_chunk,
-                    const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
-void launch_adler(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, ChunkMeta *meta, hipStream_t st);
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
+void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
                    uint64_t out_cap, hipStream_t st);
 void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st);
 bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
-void launch_lz_parallel(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, LevelCfg cfg,
-                        uint32_t pos0_mode, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
+void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
 
@@ -151,8 +148,10 @@ static void zlib_header(int level, uint8_t hdr[2]) // qcsrc/deflate.c:625-641
     hdr[0] = (uint8_t)(h >> 8); hdr[1] = (uint8_t)h;
 }
 
-static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, uint8_t *d_out,
-                          uint64_t out_cap, uint64_t *d_chunk_offsets, zgpu_deflate_result *res, hipStream_t st)
+// d_seg (optional): device table of nseg+1 offsets; then every segment is one chunk and chunk_size is ignored.
+static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_seg, uint64_t nseg,
+                          const zgpu_deflate_params *p, uint8_t *d_out, uint64_t out_cap, uint64_t *d_chunk_offsets,
+                          zgpu_deflate_result *res, hipStream_t st)
 {
     if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
@@ -166,14 +165,18 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (impl == ZGPU_LZ_PARALLEL && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     const bool serial = impl == ZGPU_LZ_SERIAL;
-    const uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1;
+    if (d_seg && ((p->flags & ZGPU_F_ZLIB_WRAP) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
+    const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
     const uint32_t batch_max = serial ? env_u32("ZGPU_SERIAL_BATCH_CHUNKS", 65536) : env_u32("ZGPU_BATCH_CHUNKS", 8192);
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
     int rc = ensure_deflate_ws(e, batch, serial, nchunks);
     if (rc) return rc;
     const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP;
-    const uint64_t final_chunk = (p->flags & ZGPU_F_FINAL) ? nchunks - 1 : ~0ull;
-    const uint32_t pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
+    ChunkGeom g{};
+    g.in = d_in; g.in_bytes = in_bytes; g.seg_off = d_seg; g.chunk_size = chunk_size;
+    g.final_chunk = (!d_seg && (p->flags & ZGPU_F_FINAL)) ? nchunks - 1 : ~0ull;
+    g.all_final = (d_seg && (p->flags & ZGPU_F_FINAL)) ? 1u : 0u;
+    g.pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
     const uint64_t body_cap = wrap ? (out_cap >= 6 ? out_cap - 4 : 0) : out_cap;
 
     RunStateHost rs{}; rs.out_total = wrap ? 2 : 0; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
@@ -182,21 +185,22 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        g.chunk0 = c0; g.nchunks = nb;
         if (serial) {
             StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
-            launch_lz_serial(d_in, in_bytes, chunk_size, c0, nb, cfg, pos0_mode, e->tables, e->tokens, e->meta, st);
+            launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            launch_lz_parallel(d_in, in_bytes, chunk_size, c0, nb, cfg, pos0_mode, e->par_ws, e->tokens, e->meta, st, e);
+            launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
             ZGPU_HIP_CHECK(hipMemsetAsync(e->slots, 0, (size_t)nb * kSlotStride, st));
-            launch_huffman(d_in, chunk_size, c0, nb, final_chunk, e->tokens, e->meta, e->slots, st);
+            launch_huffman(g, e->tokens, e->meta, e->slots, st);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
-            launch_adler(d_in, in_bytes, chunk_size, c0, nb, e->meta, st);
+            launch_adler(g, e->meta, st);
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st);
             launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, st);
         }
@@ -295,7 +299,7 @@ int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, con
 {
     if (!e) return ZGPU_STREAM_ERROR;
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
-    return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, p, static_cast<uint8_t *>(d_out), out_cap, d_chunk_offsets, res, st);
+    return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, nullptr, 0, p, static_cast<uint8_t *>(d_out), out_cap, d_chunk_offsets, res, st);
 }
 
 int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out, uint64_t out_cap,
@@ -308,11 +312,45 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
     int rc = ensure_stage(e, in_bytes, bound);
     if (rc) return rc;
     if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
-    rc = deflate_device(e, e->stage_in, in_bytes, p, e->stage_out, bound, nullptr, res, e->stream);
+    rc = deflate_device(e, e->stage_in, in_bytes, nullptr, 0, p, e->stage_out, bound, nullptr, res, e->stream);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
     if (chunk_offsets) ZGPU_HIP_CHECK(hipMemcpyAsync(chunk_offsets, e->offsets, (res->nchunks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ZGPU_OK;
+}
+
+int zgpu_deflate_segments_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_seg_offsets, uint64_t nseg,
+                                 const zgpu_deflate_params *p, void *d_out, uint64_t out_cap, uint64_t *d_out_offsets,
+                                 zgpu_deflate_result *res, void *hip_stream)
+{
+    if (!e || !d_seg_offsets) return ZGPU_STREAM_ERROR;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, d_seg_offsets, nseg, p, static_cast<uint8_t *>(d_out), out_cap,
+                          d_out_offsets, res, st);
+}
+
+int zgpu_deflate_segments_host(zgpu_engine *e, const void *in, const uint64_t *seg_offsets, uint64_t nseg, const zgpu_deflate_params *p,
+                               void *out, uint64_t out_cap, uint64_t *out_offsets, zgpu_deflate_result *res)
+{
+    if (!e || !p || !res || !in || !out || !seg_offsets || nseg == 0) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    const uint64_t in_bytes = seg_offsets[nseg];
+    for (uint64_t k = 0; k < nseg; k++)
+        if (seg_offsets[k + 1] < seg_offsets[k] || seg_offsets[k + 1] - seg_offsets[k] > kChunkMax) return fail(e, ZGPU_STREAM_ERROR, "segment longer than 65536 bytes");
+    const uint64_t bound = in_bytes + nseg * 40 + 16;
+    int rc = ensure_stage(e, in_bytes + (nseg + 1) * sizeof(uint64_t) + 64, bound);
+    if (rc) return rc;
+    const uint64_t tab_off = (in_bytes + 63) & ~63ull; // segment table staged behind the data
+    if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in + tab_off, seg_offsets, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    rc = deflate_device(e, e->stage_in, in_bytes, reinterpret_cast<const uint64_t *>(e->stage_in + tab_off), nseg, p, e->stage_out, bound,
+                        nullptr, res, e->stream);
+    if (rc) return rc;
+    if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (out_offsets) ZGPU_HIP_CHECK(hipMemcpyAsync(out_offsets, e->offsets, (nseg + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     return ZGPU_OK;
 }
@@ -365,7 +403,8 @@ int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uin
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
-        launch_adler(static_cast<const uint8_t *>(d_in), in_bytes, kChunkMax, c0, nb, meta, st);
+        ChunkGeom g{}; g.in = static_cast<const uint8_t *>(d_in); g.in_bytes = in_bytes; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
+        launch_adler(g, meta, st);
         launch_scan(meta, nb, c0, offs, e->run, ~0ull, st);
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));

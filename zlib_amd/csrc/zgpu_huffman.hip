@@ -183,11 +183,13 @@ __device__ inline void token_bits(uint32_t t, const uint16_t *lcode, const uint8
     if (dist == 0) { bits = lcode[lc]; nb = llen[lc]; return; }
     uint32_t c = kTables.len_code[lc], s = 257 + c;
     bits = lcode[s]; nb = llen[s];
-    bits |= (uint64_t)(lc - kTables.base_len[c]) << nb; nb += kTables.xl[c];
+    const uint32_t xl = kTables.xl[c];
+    if (xl) { bits |= (uint64_t)(lc - kTables.base_len[c]) << nb; nb += xl; } // length 258 (code 28) has base 0 and no extra bits
     dist--;
     uint32_t dc = dist_code_of(dist);
     bits |= (uint64_t)dcode[dc] << nb; nb += dlen[dc];
-    bits |= (uint64_t)(dist - kTables.base_dist[dc]) << nb; nb += kTables.xd[dc];
+    const uint32_t xd = kTables.xd[dc];
+    if (xd) { bits |= (uint64_t)(dist - kTables.base_dist[dc]) << nb; nb += xd; }
 }
 
 __device__ inline uint32_t block_reduce_add(uint32_t v, uint32_t *tmp)
@@ -213,26 +215,26 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     return base + x - v;
 }
 
-__global__ void __launch_bounds__(kThreads) huffman_kernel(const uint8_t *__restrict__ in, uint32_t chunk_size, uint64_t chunk0,
-                                                           uint32_t nchunks, uint64_t final_chunk, const uint32_t *__restrict__ tokens,
-                                                           ChunkMeta *meta, uint8_t *slots)
+__global__ void __launch_bounds__(kThreads) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots)
 {
     __shared__ TreeWork work[2];
     __shared__ uint32_t hist[kLCodes + kDCodes + 2];
     __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
     __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
     __shared__ uint32_t tmp[4];
+    __shared__ uint8_t five[kDCodes];
     __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
     __shared__ uint64_t sh_bitpos;
 
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    if (c >= nchunks) return;
-    const uint64_t gc = chunk0 + c;
-    const uint8_t *src = in + gc * chunk_size;
+    if (c >= g.nchunks) return;
+    uint64_t lo; uint32_t nbytes;
+    chunk_span(g, c, lo, nbytes);
+    const uint8_t *src = g.in + lo;
     const uint32_t *tok = tokens + (size_t)c * kChunkMax;
     uint32_t *out = reinterpret_cast<uint32_t *>(slots + (size_t)c * kSlotStride);
     const uint32_t ntok = meta[c].ntok, nostore = meta[c].nostore;
-    const bool final_chunk_here = (gc == final_chunk);
+    const bool final_chunk_here = chunk_is_final(g, c);
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = 0, data_type = 2;
     if (tid == 0) sh_bitpos = 0;
@@ -267,7 +269,6 @@ __global__ void __launch_bounds__(kThreads) huffman_kernel(const uint8_t *__rest
             sh_lmax = (uint32_t)build_tree(work[0], kLCodes, kTables.sl_len, kTables.xl, 257, kMaxBits, lcode, llen, o, s);
             sh_optl = o; sh_statl = s;
         } else if (tid == 64) {
-            __shared__ uint8_t five[kDCodes];
             for (int i = 0; i < kDCodes; i++) five[i] = 5;
             uint32_t o = 0, s = 0;
             sh_dmax = (uint32_t)build_tree(work[1], kDCodes, five, kTables.xd, 0, kMaxBits, dcode, dlen, o, s);
@@ -349,11 +350,9 @@ __global__ void __launch_bounds__(kThreads) huffman_kernel(const uint8_t *__rest
     }
 }
 
-void launch_huffman(const uint8_t *in, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, uint64_t final_chunk,
-                    const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st)
+void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st)
 {
-    hipLaunchKernelGGL(huffman_kernel, dim3(nchunks), dim3(kThreads), 0, st, in, chunk_size, chunk0, nchunks, final_chunk, tokens, meta,
-                       slots);
+    hipLaunchKernelGGL(huffman_kernel, dim3(g.nchunks), dim3(kThreads), 0, st, g, tokens, meta, slots);
 }
 
 } // namespace zgpu

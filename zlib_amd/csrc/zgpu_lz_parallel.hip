@@ -3,5 +3,5 @@
 namespace zgpu {
 bool lz_parallel_available() { return false; }
 size_t lz_parallel_workspace_bytes(uint32_t) { return 256; }
-void launch_lz_parallel(const uint8_t *, uint64_t, uint32_t, uint64_t, uint32_t, LevelCfg, uint32_t, void *, uint32_t *, ChunkMeta *, hipStream_t, void *) {}
+void launch_lz_parallel(const ChunkGeom &, LevelCfg, void *, uint32_t *, ChunkMeta *, hipStream_t, void *) {}
 } // namespace zgpu

@@ -122,17 +122,15 @@ __device__ void lz_serial_chunk(SerialLz &s)
 }
 
 // grid: one lane per chunk of the batch.  tables: per chunk 2 x 32768 u16 (head zeroed by the host side).
-__global__ void __launch_bounds__(64) lz_serial_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint32_t chunk_size,
-                                                       uint64_t chunk0, uint32_t nchunks, LevelCfg cfg, uint32_t pos0_mode,
-                                                       uint16_t *tables, uint32_t *tokens, ChunkMeta *meta)
+__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta)
 {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    uint64_t gc = chunk0 + c, lo = gc * chunk_size;
-    uint64_t rem = in_bytes - lo;
+    if (c >= g.nchunks) return;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
     SerialLz s;
-    s.in = in + lo; s.n = (uint32_t)(rem < chunk_size ? rem : chunk_size);
-    s.base = (pos0_mode == 2 || (pos0_mode == 1 && gc != 0)) ? 3u : 0u; s.off = 0;
+    s.in = g.in + lo; s.n = n;
+    s.base = chunk_base(g, c); s.off = 0;
     s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = 0; s.cfg = cfg;
@@ -140,12 +138,9 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(const uint8_t *__restrict
     meta[c].ntok = s.ntok; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
 }
 
-void launch_lz_serial(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks,
-                      LevelCfg cfg, uint32_t pos0_mode, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
 {
-    dim3 grid((nchunks + 63) / 64), block(64);
-    hipLaunchKernelGGL(lz_serial_kernel, grid, block, 0, st, in, in_bytes, chunk_size, chunk0, nchunks, cfg, pos0_mode, tables,
-                       tokens, meta);
+    hipLaunchKernelGGL(lz_serial_kernel, dim3((g.nchunks + 63) / 64), dim3(64), 0, st, g, cfg, tables, tokens, meta);
 }
 
 } // namespace zgpu

@@ -21,16 +21,15 @@ struct RunState {
 };
 
 // ---- Adler-32 of each chunk: A = 1 + sum b_i, B = n + sum (n - i) b_i (mod 65521) ----
-__global__ void __launch_bounds__(256) adler_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0,
-                                                    uint32_t nchunks, ChunkMeta *meta)
+__global__ void __launch_bounds__(256) adler_kernel(ChunkGeom g, ChunkMeta *meta)
 {
     __shared__ uint64_t red2[4];
     __shared__ uint32_t red1[4];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    if (c >= nchunks) return;
-    const uint64_t lo = (chunk0 + c) * (uint64_t)chunk_size, rem = in_bytes - lo;
-    const uint32_t n = (uint32_t)(rem < chunk_size ? rem : chunk_size);
-    const uint8_t *src = in + lo;
+    if (c >= g.nchunks) return;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
     uint32_t s1 = 0; uint64_t s2 = 0;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const uint4 *v = reinterpret_cast<const uint4 *>(src);
@@ -133,9 +132,9 @@ __global__ void __launch_bounds__(64) corpus_kernel(uint32_t kind, uint64_t seed
     if (i < nchunks) zc_fill_chunk(kind, seed, first_chunk + i, out + i * ZC_CHUNK);
 }
 
-void launch_adler(const uint8_t *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t chunk0, uint32_t nchunks, ChunkMeta *meta, hipStream_t st)
+void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)
 {
-    hipLaunchKernelGGL(adler_kernel, dim3(nchunks), dim3(256), 0, st, in, in_bytes, chunk_size, chunk0, nchunks, meta);
+    hipLaunchKernelGGL(adler_kernel, dim3(g.nchunks), dim3(256), 0, st, g, meta);
 }
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st)
 {

@@ -56,6 +56,8 @@ def load_library():
     L.zgpu_deflate_bound.restype = u64
     L.zgpu_deflate_device.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
+    L.zgpu_deflate_segments_host.argtypes = [vp, vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
+    L.zgpu_deflate_segments_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
     L.zgpu_inflate_host.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
     L.zgpu_inflate_find_chunks_host.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64)]
@@ -118,6 +120,24 @@ class Engine:
         self.last = res
         z = out[: res.out_bytes].tobytes()
         return (z, offs) if want_offsets else z
+
+    def deflate_segments_host(self, buffers, level, flags=0, lz_impl=LZ_AUTO):
+        """Batch of independent buffers (each <= 65536 bytes) -> list of raw-deflate segments, one launch."""
+        import numpy as np
+        sizes = [len(b) for b in buffers]
+        offs = np.zeros(len(buffers) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(sizes)
+        blob = np.frombuffer(b"".join(buffers) + b"\0", dtype=np.uint8)
+        cap = int(offs[-1]) + 40 * len(buffers) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        ooffs = np.zeros(len(buffers) + 1, dtype=np.uint64)
+        p = _Params(level, 0, flags, lz_impl)
+        res = DeflateResult()
+        self._check(self.L.zgpu_deflate_segments_host(self.h, blob.ctypes.data, offs.ctypes.data, len(buffers), C.byref(p),
+                                                      out.ctypes.data, cap, ooffs.ctypes.data, C.byref(res)))
+        self.last = res
+        raw = out[: res.out_bytes].tobytes()
+        return [raw[int(ooffs[i]): int(ooffs[i + 1])] for i in range(len(buffers))]
 
     def deflate_device(self, d_in, n, level, d_out, out_cap, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO,
                        d_offsets=None, stream=None):
