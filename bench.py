@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- GiB/s of raw input compressed (deflate level 6) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 4 GiB of the seeded synthetic Silesia-mix per GPU (65 536 chunks of 64 KiB,
+zlib_amd/csrc/corpus.h), generated directly in HBM before the timed region.  A step = one pass of the hot path over
+that batch: LZ77 + Huffman + stitch into one RFC 1950 stream per GPU; for N > 1 the per-GPU streams are gathered
+to rank 0 over RCCL inside the step (the path's only exchange).  Weak scaling: rank r compresses chunks
+[r*65536, (r+1)*65536) of the corpus.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel stage, timed with HIP events on the launch
+stream (zgpu_profile_*); `cpu_baseline` is the compiled reference (or the repo's CPU restatement when
+oracle/_ref is absent) timed on the host cores over a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--gib", type=float, default=4.0, help="GiB of input per GPU")
+    ap.add_argument("--workload", default="silesia-mix", choices=["silesia-mix", "log-text"])
+    ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel"])
+    ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample, level, threads):
+    """Time the reference (oracle/_ref) -- or the CPU restatement -- per 64 KiB chunk on `threads` host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import refzlib, oracle_py
+    use_ref = refzlib.available()
+    nchunks = len(sample) // 65536
+    if use_ref:
+        refzlib.lib()
+
+        def work(r):
+            n = 0
+            for k in r:
+                n += len(refzlib.deflate_chunk_raw(sample[k * 65536:(k + 1) * 65536], level, False))
+            return n
+    else:
+        oracle_py.lib()
+
+        def work(r):
+            n = 0
+            for k in r:
+                n += len(oracle_py.deflate_chunk(sample[k * 65536:(k + 1) * 65536], level, False))
+            return n
+    parts = [range(t, nchunks, threads) for t in range(threads)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        out_bytes = sum(ex.map(work, parts))
+    dt = time.perf_counter() - t0
+    return {"value": round(len(sample) / dt / 2**30, 4), "unit": "GiB/s", "cores": threads,
+            "kind": "reference" if use_ref else "port",
+            "sample": "first %d MiB of the workload, 64 KiB chunks, level %d, %.1f s wall, ratio %.3f" % (
+                len(sample) >> 20, level, dt, len(sample) / out_bytes)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import zlib_amd
+    from zlib_amd import gpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    eng = zlib_amd.Engine(local)
+    kind = 0 if a.workload == "silesia-mix" else 1
+    seed = 0x5EED5117 if kind == 0 else 0x10C7E47
+    nchunks = int(a.gib * 2**30) // 65536
+    nbytes = nchunks * 65536
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    eng.corpus_fill_device(kind, seed, rank * nchunks, nchunks, src.data_ptr())
+    cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
+    dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+    lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL}[a.lz]
+    stream = torch.cuda.current_stream().cuda_stream
+    gather_buf = None
+    state = {}
+
+    def deflate_step():
+        res = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
+                                 lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
+        state["res"] = res
+        if world > 1:
+            # gather-v of the per-GPU streams to rank 0: sizes first, then point-to-point sends (one xGMI link per peer)
+            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+            mine = torch.tensor([res.out_bytes], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sizes, mine)
+            sz = sizes.tolist()
+            nonlocal gather_buf
+            if rank == 0:
+                total = sum(sz)
+                if gather_buf is None or gather_buf.numel() < total:
+                    gather_buf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=dev)
+                gather_buf[: sz[0]].copy_(dst[: sz[0]])
+                reqs, o = [], sz[0]
+                for r in range(1, world):
+                    reqs.append(dist.irecv(gather_buf[o: o + sz[r]], src=r))
+                    o += sz[r]
+                for q in reqs:
+                    q.wait()
+                state["gathered"] = total
+            else:
+                dist.send(dst[: res.out_bytes], dst=0)
+
+    def inflate_step():
+        r = eng.inflate_device(state["z_ptr"], state["z_len"], offs.data_ptr(), nchunks, src2.data_ptr(), nbytes, stream=stream)
+        state["ires"] = r
+
+    step = deflate_step
+    if a.op == "inflate":
+        deflate_step()
+        res = state["res"]
+        # raw body without the 2-byte header: offsets are relative to the stream start, which includes the header
+        state["z_ptr"], state["z_len"] = dst.data_ptr(), res.out_bytes
+        src2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        step = inflate_step
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if a.op == "inflate":
+        ok = bool(torch.equal(src, src2))
+        if not ok:
+            sys.exit("inflate output differs from the original input")
+
+    if rank == 0:
+        res = state["res"]
+        ratio = nbytes / res.out_bytes
+        total_in = nbytes * world * a.steps
+        value = total_in / dt / 2**30
+        # dominant stage by device time
+        stages = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(stages, key=lambda k: stages[k][0]) if stages else None
+        roof = None
+        if dom:
+            ms, launches = stages[dom]
+            per_launch_bytes = (nbytes + res.out_bytes) * a.steps / launches  # algorithmic: input read + stream written
+            achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+                    "stage_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in stages.items()}}
+        line = {
+            "metric": "GiB/s raw input %s (deflate level %d)" % ("decompressed" if a.op == "inflate" else "compressed", a.level),
+            "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s %.2f GiB per GPU, 64 KiB independent chunks, level %d, bit-exact vs zlib 1.2.3" % (
+                a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
+                "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
+                "gathered_bytes": int(state.get("gathered", res.out_bytes))},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            sample_bytes = min(nbytes, a.cpu_sample_mib << 20)
+            sample = src[:sample_bytes].cpu().numpy().tobytes()
+            threads = min(16, os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(sample, a.level, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

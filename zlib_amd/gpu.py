@@ -40,6 +40,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process.  The torch wheel bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's);
+    # whichever is mapped first serves both, so when torch is installed it must come first -- loading the system
+    # runtime first and torch's afterwards leaves two runtimes in the process and torch then sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError("%s is missing: build it with `make -C zlib_amd/csrc` (or __graft_entry__.build())" % path)
