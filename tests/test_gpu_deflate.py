@@ -27,7 +27,7 @@ def impls(level):
     return [gpu.LZ_SERIAL] + ([gpu.LZ_PARALLEL] if level >= 4 and PARALLEL else [])
 
 
-PARALLEL = False
+PARALLEL = True
 
 
 def split_chunks(z, offs):
