@@ -1,0 +1,40 @@
+"""Summarise rocprofv3 csv output (kernel stats + PMC counters per kernel) into one text table."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def find(pattern):
+    return glob.glob(os.path.join(root, "**", pattern), recursive=True)
+
+
+print("== kernel stats ==")
+for f in find("*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("%-70s calls %6s total_ms %10.3f avg_us %12.3f pct %6s" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                          float(r["AverageNs"]) / 1e3, r["Percentage"]))
+print("== pmc (sum over dispatches, per kernel) ==")
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(int)
+for f in find("*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, d in agg.items():
+    print(k)
+    for c in sorted(d):
+        print("    %-28s %18.0f" % (c, d[c]))
+    if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
+        wc = d["SQ_WAVE_CYCLES"]
+        for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if c in d:
+                print("    %-28s %17.1f%% of wave cycles" % (c, 100 * d[c] / wc))
+    if "SQ_LDS_IDX_ACTIVE" in d and d["SQ_LDS_IDX_ACTIVE"]:
+        print("    bank-conflict share of LDS-active cycles: %.1f%%" % (100 * d.get("SQ_LDS_BANK_CONFLICT", 0) / d["SQ_LDS_IDX_ACTIVE"]))
+    if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"]:
+        print("    VALU lane utilisation: %.1f%%" % (100 * d["SQ_THREAD_CYCLES_VALU"] / (64 * d["SQ_ACTIVE_INST_VALU"])))

@@ -30,7 +30,7 @@ void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 
 constexpr uint32_t kNoLink = 0xFFFFu;
-constexpr uint32_t kTile = 4096, kRingTiles = 10, kRing = kTile * kRingTiles; // 40960 links = 80 KiB
+constexpr uint32_t kTile = 8192, kRing = 40960; // ring >= MAX_DIST + tile: 40960 links = 80 KiB
 constexpr uint32_t kMatchThreads = 1024;
 
 struct ParWorkspace { uint16_t *links; uint2 *recs; };
@@ -81,28 +81,23 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------- K2
-__device__ inline uint32_t ring_slot(uint32_t q)
-{
-    uint32_t t = q >> 12;
-    t = t >= kRingTiles ? t - kRingTiles : t;
-    return t * kTile + (q & (kTile - 1));
-}
+// The ring keeps the links of the most recent kRing positions: slot(q) = q mod kRing (q < 65536 < 2*kRing).
+__device__ inline uint32_t ring_slot(uint32_t q) { return q >= kRing ? q - kRing : q; }
 
-// 4 bytes at any byte offset of the LDS copy of the chunk
-__device__ inline uint32_t lds_load32u(const uint32_t *d32, uint32_t a)
-{
-    const uint32_t i = a >> 2;
-    return __builtin_amdgcn_alignbyte(d32[i + 1], d32[i], a & 3);
-}
+// Lane states of the walk: every wave iteration advances each lane by one unit of work, either one chain
+// candidate (quick reject + link hop) or one 8-byte piece of a full comparison, so the lanes of a wave never wait
+// for one lane's inner loop.  Idle lanes are refilled with new positions in groups.
+enum : uint32_t { kIdle = 0, kWalk = 1, kCmp = 2 };
 
 __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ links, uint2 *__restrict__ recs)
 {
     extern __shared__ uint32_t lds[];
-    uint32_t *d32 = lds;                                        // 65536 + 64 bytes of chunk data
+    uint32_t *d32 = lds;                                                       // 65536 + 64 bytes of chunk data
     uint16_t *ring = reinterpret_cast<uint16_t *>(lds + (kChunkMax + 64) / 4); // kRing links
+    uint32_t *tile_next = lds + (kChunkMax + 64) / 4 + kRing / 2;              // work counter of the current tile
     const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
 
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
@@ -111,14 +106,19 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
     const uint32_t base = chunk_base(g, c);
 
     // stage the chunk (zero padded) in LDS
-    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-        const uint32_t nw = n >> 2;
-        for (uint32_t i = tid; i < (kChunkMax + 64) / 4; i += kMatchThreads) {
-            uint32_t v = 0;
-            if (i < nw) v = s32[i];
-            else if (i == nw) { for (uint32_t k = 0; k < (n & 3); k++) v |= (uint32_t)src[(nw << 2) + k] << (8 * k); }
-            d32[i] = v;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *s128 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d128 = reinterpret_cast<uint4 *>(d32);
+        const uint32_t nv = n >> 4;
+        for (uint32_t i = tid; i < (kChunkMax + 64) / 16; i += kMatchThreads) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < nv) v = s128[i];
+            else if (i == nv) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < (n & 15); k++) w[k >> 2] |= (uint32_t)src[(nv << 4) + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            d128[i] = v;
         }
     } else {
         for (uint32_t i = tid; i < (kChunkMax + 64) / 4; i += kMatchThreads) {
@@ -129,48 +129,107 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
     }
     const uint32_t ntiles = (n + kTile - 1) / kTile;
     const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2;
+
     for (uint32_t t = 0; t < ntiles; t++) {
-        __syncthreads(); // previous tile's walks are done; tile t-10's slot is dead
-        for (uint32_t i = tid; i < kTile; i += kMatchThreads) { uint32_t q = t * kTile + i; ring[ring_slot(q)] = q < n ? lk[q] : (uint16_t)kNoLink; }
-        __syncthreads();
-        for (uint32_t j = 0; j < kTile / kMatchThreads; j++) {
-            const uint32_t p = t * kTile + j * kMatchThreads + tid;
-            if (p >= n) continue;
-            uint32_t lenF = 0, distF = 0, lenQ = 0, distQ = 0, flags = 0;
-            if (p + 3 <= n) {
-                const uint32_t look = n - p, cap = look < kMaxMatch ? look : kMaxMatch;
-                const uint32_t nice = cfg.nice < look ? cfg.nice : look;
-                const int w = (int)(p + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
-                uint32_t q = ring[ring_slot(p)];
-                // first candidate: not NIL (window index 0) and within MAX_DIST (deflate.c:1588-1589)
-                bool go = q != kNoLink && (int)(q + base) > 0 && (uint32_t)(w - (int)(q + base)) <= kMaxDist;
-                if (go && q + base == kWSize) flags |= 1u;
-                uint32_t best = kMinMatch - 1, bestq = 0, steps = 0;
-                bool snapped = false;
-                while (go) {
-                    // quick reject on the byte that would extend the current best (deflate.c:1121-1124)
-                    if (best < cap && d8[q + best] == d8[p + best]) {
-                        uint32_t l = 0;
-                        while (l < cap) {
-                            uint32_t x = lds_load32u(d32, q + l) ^ lds_load32u(d32, p + l);
-                            if (x) { l += (uint32_t)(__ffs((int)x) - 1) >> 3; break; }
-                            l += 4;
-                        }
-                        if (l > cap) l = cap;
-                        if (l > best) { best = l; bestq = q; }
-                    }
-                    steps++;
-                    if (steps == chainQ) { lenQ = best; distQ = p - bestq; snapped = true; }
-                    if (best >= nice || steps == chainF) break;
-                    q = ring[ring_slot(q)];
-                    go = q != kNoLink && (int)(q + base) > limit;
-                }
-                if (!snapped) { lenQ = best; distQ = p - bestq; }
-                lenF = best; distF = p - bestq;
-                if (lenF < kMinMatch) { lenF = 0; distF = 0; }
-                if (lenQ < kMinMatch) { lenQ = 0; distQ = 0; }
+        const uint32_t tile_lo = t * kTile, tile_hi = tile_lo + kTile < n ? tile_lo + kTile : n;
+        __syncthreads(); // the previous tile's walks are done: the slots this tile overwrites are dead
+        {   // kTile links -> ring, 8 per lane (tile_lo is a multiple of 8 and so is its slot)
+            const uint32_t q0 = tile_lo + tid * 8;
+            uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (q0 + 8 <= n) v = *reinterpret_cast<const uint4 *>(lk + q0);
+            else if (q0 < n) {
+                uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                for (uint32_t k = 0; q0 + k < n; k++) w[k >> 1] = (w[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | ((uint32_t)lk[q0 + k] << (16 * (k & 1)));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            rec[p] = make_uint2(lenF | (distF << 9) | ((uint32_t)d8[p] << 24), lenQ | (distQ << 9) | (flags << 24));
+            *reinterpret_cast<uint4 *>(ring + ring_slot(q0)) = v;
+            if (tid == 0) *tile_next = tile_lo;
+        }
+        __syncthreads();
+
+        // per-lane walk state
+        uint32_t mode = kIdle, p = 0, q = 0, best = 0, bestq = 0, steps = 0, snap = 0, l = 0, cap = 0, nice = 0, flags = 0;
+        uint32_t chk_off = 0, chk_mask = 0, chk_word = 0;
+        int limit = 0;
+        uint64_t scan0 = 0;
+        uint32_t sup_next = 0, sup_end = 0; // this wave's private supply of positions (wave-uniform)
+        bool tile_dry = false;
+
+        for (;;) {
+            const unsigned long long idle = __ballot(mode == kIdle);
+            if (idle) {
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                if (sup_next == sup_end && !tile_dry) { // fetch another 128 positions for this wave
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(tile_next, 128u);
+                    got = __shfl(got, 0);
+                    if (got >= tile_hi) tile_dry = true;
+                    else { sup_next = got; sup_end = got + 128 < tile_hi ? got + 128 : tile_hi; }
+                }
+                const bool have = sup_next != sup_end;
+                if (!have && nidle == 64) break;
+                if (have && (nidle >= 16 || nidle == 64)) {
+                    if (mode == kIdle) {
+                        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1));
+                        const uint32_t np = sup_next + rank;
+                        if (np < sup_end) {
+                            p = np;
+                            const uint32_t look = n - p;
+                            cap = look < kMaxMatch ? look : kMaxMatch;
+                            nice = cfg.nice < look ? cfg.nice : look;
+                            const int w = (int)(p + base);
+                            limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+                            q = ring[ring_slot(p)];
+                            scan0 = *reinterpret_cast<const uint64_t *>(d8 + p);
+                            const bool valid = look >= kMinMatch && q != kNoLink && (int)(q + base) > 0 && (uint32_t)(w - (int)(q + base)) <= kMaxDist;
+                            flags = (valid && q + base == kWSize) ? 1u : 0u;
+                            best = kMinMatch - 1; bestq = p; steps = 0; snap = 0;
+                            chk_off = 0; chk_mask = 0x00FFFFFFu; chk_word = (uint32_t)scan0 & 0x00FFFFFFu;
+                            if (valid) mode = kWalk;
+                            else rec[p] = make_uint2((uint32_t)(scan0 & 0xFF) << 24, 0); // no candidate at all
+                        }
+                    }
+                    const uint32_t take = nidle < sup_end - sup_next ? nidle : sup_end - sup_next;
+                    sup_next += take;
+                }
+            }
+            bool hop = false;
+            if (mode == kCmp) {
+                const uint64_t a = *reinterpret_cast<const uint64_t *>(d8 + q + l);
+                const uint64_t b = l == 0 ? scan0 : *reinterpret_cast<const uint64_t *>(d8 + p + l);
+                const uint64_t x = a ^ b;
+                if (x == 0 && l + 8 < cap) l += 8;
+                else {
+                    uint32_t len = x ? l + ((uint32_t)__builtin_ctzll(x) >> 3) : l + 8;
+                    len = len < cap ? len : cap;
+                    if (len > best) {
+                        best = len; bestq = q;
+                        chk_off = best - 3; chk_mask = 0xFFFFFFFFu; // bytes best-3 .. best must match for a longer match
+                        chk_word = *reinterpret_cast<const uint32_t *>(d8 + p + chk_off);
+                    }
+                    mode = kWalk; hop = true;
+                }
+            } else if (mode == kWalk) {
+                const uint32_t cw = *reinterpret_cast<const uint32_t *>(d8 + q + chk_off) & chk_mask;
+                if (cw == chk_word) { mode = kCmp; l = 0; } // candidate may be longer: compare it in full
+                else hop = true;
+            }
+            if (hop) { // candidate q is dealt with: account for it and move to the next one (deflate.c:1152-1164)
+                steps++;
+                if (steps == chainQ) snap = best | ((p - bestq) << 9);
+                bool stop = best >= nice || steps == chainF;
+                const uint32_t nq = ring[ring_slot(q)];
+                stop = stop || nq == kNoLink || (int)(nq + base) <= limit;
+                q = nq;
+                if (stop) {
+                    uint32_t full = best | ((p - bestq) << 9);
+                    if (steps < chainQ) snap = full;
+                    if ((full & 511) < kMinMatch) full = 0;
+                    if ((snap & 511) < kMinMatch) snap = 0;
+                    rec[p] = make_uint2(full | ((uint32_t)(scan0 & 0xFF) << 24), snap | (flags << 24));
+                    mode = kIdle;
+                }
+            }
         }
     }
 }
@@ -245,7 +304,7 @@ void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint3
     hipLaunchKernelGGL(chain_kernel, dim3(g.nchunks), dim3(64), 0, st, g, links);
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
-    const size_t lds_bytes = (kChunkMax + 64) + kRing * sizeof(uint16_t);
+    const size_t lds_bytes = (kChunkMax + 64) + kRing * sizeof(uint16_t) + 64;
     static bool lds_opt_in = false; // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!lds_opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); lds_opt_in = true; }
     hipLaunchKernelGGL(match_kernel, dim3(g.nchunks), dim3(kMatchThreads), lds_bytes, st, g, cfg, links, recs);
