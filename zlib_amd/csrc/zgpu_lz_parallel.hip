@@ -29,9 +29,10 @@ namespace zgpu {
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 
-constexpr uint32_t kNoLink = 0xFFFFu;
+constexpr uint32_t kNoLink = 0; // links are stored as q+1 (q = position of the previous same-hash string), 0 = none
 constexpr uint32_t kTile = 8192, kRing = 40960; // ring >= MAX_DIST + tile: 40960 links = 80 KiB
 constexpr uint32_t kMatchThreads = 1024;
+constexpr int kSlots = 1; // positions a lane walks concurrently (1 or 2)
 
 struct ParWorkspace { uint16_t *links; uint2 *recs; };
 
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *lk = links + (size_t)c * kChunkMax;
-    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0; // head[] holds p+1, 0 = empty
     __syncthreads();
     const uint32_t npos = n >= 3 ? n - 2 : 0; // positions 0 .. n-3 carry a hash
     volatile uint16_t *vhead = head; // the claim/read-back below must really go through LDS
@@ -60,21 +61,21 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
         bool last = live; // the highest lane of a hash group leaves its position in head[]
         // claim the slot (LDS executes one wave's operations in order; when several lanes hit the same slot one of them
         // lands), then read it back: a lane that does not see itself shares its hash with another lane of this step
-        if (live) vhead[h] = (uint16_t)p;
-        const uint32_t seen = live ? (uint32_t)vhead[h] : p;
-        unsigned long long clash = __ballot(live && seen != p);
+        if (live) vhead[h] = (uint16_t)(p + 1);
+        const uint32_t seen = live ? (uint32_t)vhead[h] : p + 1;
+        unsigned long long clash = __ballot(live && seen != p + 1);
         while (clash) {
             const int f = __ffsll((long long)clash) - 1;
             const uint32_t h0 = __shfl(h, f);
             const unsigned long long grp = __ballot(live && h == h0);
             if (live && h == h0) {
                 const unsigned long long below = grp & ((1ull << lane) - 1);
-                if (below) link = p0 + (63 - __clzll((long long)below)); // nearest lower lane with the same hash
+                if (below) link = p0 + (63 - __clzll((long long)below)) + 1; // nearest lower lane with the same hash
                 last = (grp >> lane) == 1ull;
             }
             clash &= ~grp;
         }
-        if (live && last) vhead[h] = (uint16_t)p;
+        if (live && last) vhead[h] = (uint16_t)(p + 1);
         if (live) lk[p] = (uint16_t)link;
     }
     for (uint32_t p = npos + lane; p < n; p += 64) lk[p] = (uint16_t)kNoLink;
@@ -84,10 +85,51 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
 // The ring keeps the links of the most recent kRing positions: slot(q) = q mod kRing (q < 65536 < 2*kRing).
 __device__ inline uint32_t ring_slot(uint32_t q) { return q >= kRing ? q - kRing : q; }
 
-// Lane states of the walk: every wave iteration advances each lane by one unit of work, either one chain
-// candidate (quick reject + link hop) or one 8-byte piece of a full comparison, so the lanes of a wave never wait
-// for one lane's inner loop.  Idle lanes are refilled with new positions in groups.
-enum : uint32_t { kIdle = 0, kWalk = 1, kCmp = 2 };
+// Lane states of the walk.  A wave alternates between three homogeneous phases so that its lanes execute the same
+// short code most of the time: WALK (one chain candidate per iteration: 1-byte quick reject + link hop, both LDS
+// reads issued together), COMPARE (4 bytes of a full comparison per iteration, entered when enough lanes wait for
+// one) and REFILL (store finished records, hand new positions to idle lanes, in groups of >= 16).
+// LDS access rule (measured, scripts/micro/lds_cost.hip): naturally aligned ds_read_u8/u16/b32 cost ~4.3 clk per
+// wave-instruction per CU with random addresses, any unaligned b32/b64 ~36 clk -- so only aligned reads are used
+// (the dword pairs below are volatile so that the compiler cannot fuse them into one unaligned ds_read_b64).
+enum : uint32_t { kIdle = 0, kWalk = 1, kCmp = 2, kDone = 3 };
+
+struct WalkLane {
+    uint32_t mode, p, q, best, bestq, steps, snap_best, snap_q, l, cap, nice, flags, scan2; // scan2: bytes p+best-1, p+best
+    int limit_q; // chain continues while (int)q > limit_q; "none" decodes to q = -1 and always stops
+};
+
+// byte offset of an LDS object inside the workgroup's LDS allocation (what the ds_* instructions address)
+__device__ inline uint32_t lds_offset(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// 4 bytes at any byte offset: one ds_read2_b32 of the two aligned dwords around it + v_alignbyte (the compiler would
+// fuse two plain dword loads into a single unaligned ds_read_b64, which is ~8x slower)
+__device__ inline uint32_t lds_load32u(uint32_t lds_byte_addr)
+{
+    uint64_t v;
+    const uint32_t a = lds_byte_addr & ~3u;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, lds_byte_addr & 3);
+}
+
+// the three loads of one walk step, issued back to back with a single wait: the two quick-reject bytes of the
+// candidate and its chain link
+__device__ inline void lds_walk_loads(uint32_t addr_b0, uint32_t addr_ring, uint32_t &b0, uint32_t &b1, uint32_t &link)
+{
+    asm volatile("ds_read_u8 %0, %3\n\tds_read_u8 %1, %3 offset:1\n\tds_read_u16 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b0), "=&v"(b1), "=&v"(link) : "v"(addr_b0), "v"(addr_ring) : "memory");
+}
+// the same for the two positions a lane works on at once: six loads in flight behind one wait
+__device__ inline void lds_walk_loads2(uint32_t a0, uint32_t r0, uint32_t a1, uint32_t r1, uint32_t &x0, uint32_t &y0, uint32_t &l0,
+                                       uint32_t &x1, uint32_t &y1, uint32_t &l1)
+{
+    asm volatile("ds_read_u8 %0, %6\n\tds_read_u8 %1, %6 offset:1\n\tds_read_u16 %2, %7\n\t"
+                 "ds_read_u8 %3, %8\n\tds_read_u8 %4, %8 offset:1\n\tds_read_u16 %5, %9\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(y0), "=&v"(l0), "=&v"(x1), "=&v"(y1), "=&v"(l1) : "v"(a0), "v"(r0), "v"(a1), "v"(r1) : "memory");
+}
 
 __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ links, uint2 *__restrict__ recs)
 {
@@ -135,11 +177,11 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
         __syncthreads(); // the previous tile's walks are done: the slots this tile overwrites are dead
         {   // kTile links -> ring, 8 per lane (tile_lo is a multiple of 8 and so is its slot)
             const uint32_t q0 = tile_lo + tid * 8;
-            uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            uint4 v = make_uint4(0, 0, 0, 0);
             if (q0 + 8 <= n) v = *reinterpret_cast<const uint4 *>(lk + q0);
             else if (q0 < n) {
-                uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                for (uint32_t k = 0; q0 + k < n; k++) w[k >> 1] = (w[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | ((uint32_t)lk[q0 + k] << (16 * (k & 1)));
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; q0 + k < n; k++) w[k >> 1] |= (uint32_t)lk[q0 + k] << (16 * (k & 1));
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
             *reinterpret_cast<uint4 *>(ring + ring_slot(q0)) = v;
@@ -147,87 +189,138 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
         }
         __syncthreads();
 
-        // per-lane walk state
-        uint32_t mode = kIdle, p = 0, q = 0, best = 0, bestq = 0, steps = 0, snap = 0, l = 0, cap = 0, nice = 0, flags = 0;
-        uint32_t chk_off = 0, chk_mask = 0, chk_word = 0;
-        int limit = 0;
-        uint64_t scan0 = 0;
+        // A lane can work on kSlots positions at once ("slot" = one of the 64*kSlots walks of a wave).  Measured on MI355X:
+        // kSlots = 2 (six LDS loads in flight per lane) is 25 % slower than kSlots = 1, the walk is issue-bound, not
+        // latency-bound, so 1 it is.
+        WalkLane s[kSlots];
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) s[j] = WalkLane{};
         uint32_t sup_next = 0, sup_end = 0; // this wave's private supply of positions (wave-uniform)
         bool tile_dry = false;
+        const uint32_t dbase = lds_offset(d32), rbase = lds_offset(ring);
 
         for (;;) {
-            const unsigned long long idle = __ballot(mode == kIdle);
-            if (idle) {
-                const uint32_t nidle = (uint32_t)__popcll(idle);
-                if (sup_next == sup_end && !tile_dry) { // fetch another 128 positions for this wave
-                    uint32_t got = 0;
-                    if (lane == 0) got = atomicAdd(tile_next, 128u);
-                    got = __shfl(got, 0);
-                    if (got >= tile_hi) tile_dry = true;
-                    else { sup_next = got; sup_end = got + 128 < tile_hi ? got + 128 : tile_hi; }
+            uint32_t nw = 0, nc = 0;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) { nw += (uint32_t)__popcll(__ballot(s[j].mode == kWalk)); nc += (uint32_t)__popcll(__ballot(s[j].mode == kCmp)); }
+            const uint32_t nfree = 64 * kSlots - nw - nc;
+
+            // ---- REFILL: store finished records, hand out new positions ----
+            if (nfree >= 16 * kSlots || nw + nc == 0) {
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) {
+                    WalkLane &z = s[j];
+                    if (z.mode == kDone) {
+                        uint32_t full = z.best | ((z.p - z.bestq) << 9), snap = z.snap_best | ((z.p - z.snap_q) << 9);
+                        if (z.steps < chainQ) snap = full;
+                        if (z.best < kMinMatch) full = 0;
+                        if ((snap & 511) < kMinMatch) snap = 0;
+                        rec[z.p] = make_uint2(full | ((uint32_t)d8[z.p] << 24), snap | (z.flags << 24));
+                        z.mode = kIdle;
+                    }
                 }
-                const bool have = sup_next != sup_end;
-                if (!have && nidle == 64) break;
-                if (have && (nidle >= 16 || nidle == 64)) {
-                    if (mode == kIdle) {
-                        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1));
-                        const uint32_t np = sup_next + rank;
+                for (int round = 0; round < 4 * kSlots; round++) {
+                    const int j = round % kSlots;
+                    WalkLane &z = s[j];
+                    const unsigned long long idle = __ballot(z.mode == kIdle);
+                    const uint32_t nidle = (uint32_t)__popcll(idle);
+                    if (nidle == 0) continue;
+                    if (sup_next == sup_end && !tile_dry) { // fetch another batch of positions for this wave
+                        uint32_t got = 0;
+                        if (lane == 0) got = atomicAdd(tile_next, 256u * kSlots);
+                        got = __shfl(got, 0);
+                        if (got >= tile_hi) tile_dry = true;
+                        else { sup_next = got; sup_end = got + 256 * kSlots < tile_hi ? got + 256 * kSlots : tile_hi; }
+                    }
+                    if (sup_next == sup_end) break;
+                    if (z.mode == kIdle) {
+                        const uint32_t np = sup_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
                         if (np < sup_end) {
-                            p = np;
-                            const uint32_t look = n - p;
-                            cap = look < kMaxMatch ? look : kMaxMatch;
-                            nice = cfg.nice < look ? cfg.nice : look;
-                            const int w = (int)(p + base);
-                            limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
-                            q = ring[ring_slot(p)];
-                            scan0 = *reinterpret_cast<const uint64_t *>(d8 + p);
-                            const bool valid = look >= kMinMatch && q != kNoLink && (int)(q + base) > 0 && (uint32_t)(w - (int)(q + base)) <= kMaxDist;
-                            flags = (valid && q + base == kWSize) ? 1u : 0u;
-                            best = kMinMatch - 1; bestq = p; steps = 0; snap = 0;
-                            chk_off = 0; chk_mask = 0x00FFFFFFu; chk_word = (uint32_t)scan0 & 0x00FFFFFFu;
-                            if (valid) mode = kWalk;
-                            else rec[p] = make_uint2((uint32_t)(scan0 & 0xFF) << 24, 0); // no candidate at all
+                            z.p = np;
+                            const uint32_t look = n - np;
+                            z.cap = look < kMaxMatch ? look : kMaxMatch;
+                            z.nice = cfg.nice < look ? cfg.nice : look;
+                            const int w = (int)(np + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+                            const int lq = limit - (int)base; // q + base > limit  <=>  q > lq
+                            z.limit_q = lq < -1 ? -1 : lq;
+                            z.q = (uint32_t)ring[ring_slot(np)] - 1;
+                            const bool valid = look >= kMinMatch && z.q != 0xFFFFFFFFu && (int)(z.q + base) > 0 && (uint32_t)(w - (int)(z.q + base)) <= kMaxDist;
+                            z.flags = (valid && z.q + base == kWSize) ? 1u : 0u;
+                            z.best = kMinMatch - 1; z.bestq = np; z.steps = 0; z.snap_best = 0; z.snap_q = np;
+                            z.scan2 = (uint32_t)d8[np + 1] | ((uint32_t)d8[np + 2] << 8);
+                            if (valid) z.mode = kWalk;
+                            else rec[np] = make_uint2((uint32_t)d8[np] << 24, 0); // no candidate at all
                         }
                     }
                     const uint32_t take = nidle < sup_end - sup_next ? nidle : sup_end - sup_next;
                     sup_next += take;
                 }
-            }
-            bool hop = false;
-            if (mode == kCmp) {
-                const uint64_t a = *reinterpret_cast<const uint64_t *>(d8 + q + l);
-                const uint64_t b = l == 0 ? scan0 : *reinterpret_cast<const uint64_t *>(d8 + p + l);
-                const uint64_t x = a ^ b;
-                if (x == 0 && l + 8 < cap) l += 8;
-                else {
-                    uint32_t len = x ? l + ((uint32_t)__builtin_ctzll(x) >> 3) : l + 8;
-                    len = len < cap ? len : cap;
-                    if (len > best) {
-                        best = len; bestq = q;
-                        chk_off = best - 3; chk_mask = 0xFFFFFFFFu; // bytes best-3 .. best must match for a longer match
-                        chk_word = *reinterpret_cast<const uint32_t *>(d8 + p + chk_off);
-                    }
-                    mode = kWalk; hop = true;
+                unsigned long long busy = 0;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) busy |= __ballot(s[j].mode == kWalk || s[j].mode == kCmp);
+                if (busy == 0) {
+                    if (tile_dry && sup_next == sup_end) break; // nothing left in this tile for this wave
+                    continue;                                   // only candidate-less positions so far: refill again
                 }
-            } else if (mode == kWalk) {
-                const uint32_t cw = *reinterpret_cast<const uint32_t *>(d8 + q + chk_off) & chk_mask;
-                if (cw == chk_word) { mode = kCmp; l = 0; } // candidate may be longer: compare it in full
-                else hop = true;
             }
-            if (hop) { // candidate q is dealt with: account for it and move to the next one (deflate.c:1152-1164)
-                steps++;
-                if (steps == chainQ) snap = best | ((p - bestq) << 9);
-                bool stop = best >= nice || steps == chainF;
-                const uint32_t nq = ring[ring_slot(q)];
-                stop = stop || nq == kNoLink || (int)(nq + base) <= limit;
-                q = nq;
-                if (stop) {
-                    uint32_t full = best | ((p - bestq) << 9);
-                    if (steps < chainQ) snap = full;
-                    if ((full & 511) < kMinMatch) full = 0;
-                    if ((snap & 511) < kMinMatch) snap = 0;
-                    rec[p] = make_uint2(full | ((uint32_t)(scan0 & 0xFF) << 24), snap | (flags << 24));
-                    mode = kIdle;
+
+            // ---- COMPARE: when many slots wait for a full comparison, or few can walk ----
+            if (nc >= 16 * kSlots || (nc > 0 && nw < 16 * kSlots)) {
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) {
+                    WalkLane &z = s[j];
+                    while (__ballot(z.mode == kCmp)) {
+                        if (z.mode == kCmp) {
+                            const uint32_t x = lds_load32u(dbase + z.q + z.l) ^ lds_load32u(dbase + z.p + z.l);
+                            if (x == 0 && z.l + 4 < z.cap) z.l += 4;
+                            else {
+                                uint32_t len = x ? z.l + ((uint32_t)__builtin_ctz(x) >> 3) : z.l + 4;
+                                len = len < z.cap ? len : z.cap;
+                                if (len > z.best) { z.best = len; z.bestq = z.q; z.scan2 = (uint32_t)d8[z.p + len - 1] | ((uint32_t)d8[z.p + len] << 8); }
+                                // candidate dealt with: count it and hop (deflate.c:1152-1164)
+                                z.steps++;
+                                if (z.steps == chainQ) { z.snap_best = z.best; z.snap_q = z.bestq; }
+                                const uint32_t nq = (uint32_t)ring[ring_slot(z.q)] - 1;
+                                const bool stop = z.best >= z.nice || z.steps == chainF || (int)nq <= z.limit_q;
+                                z.q = nq;
+                                z.mode = stop ? kDone : kWalk;
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- WALK: a few candidates per slot; the quick-reject bytes and the next link are fetched together ----
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bool w[kSlots], any = false;
+#pragma unroll
+                for (int j = 0; j < kSlots; j++) { w[j] = s[j].mode == kWalk; any = any || w[j]; }
+                if (any) {
+                    uint32_t x[2], y[2], e[2];
+                    if constexpr (kSlots == 1) {
+                        lds_walk_loads(dbase + s[0].q + s[0].best - 1, rbase + 2 * ring_slot(s[0].q), x[0], y[0], e[0]);
+                    } else {
+                        // a slot that is not walking still issues its loads (one asm block for both): point them at a valid address
+                        const uint32_t q0 = w[0] ? s[0].q : 0u, q1 = w[kSlots - 1] ? s[kSlots - 1].q : 0u;
+                        lds_walk_loads2(dbase + q0 + s[0].best - 1, rbase + 2 * ring_slot(q0), dbase + q1 + s[kSlots - 1].best - 1,
+                                        rbase + 2 * ring_slot(q1), x[0], y[0], e[0], x[1], y[1], e[1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kSlots; j++) {
+                        WalkLane &z = s[j];
+                        if (w[j]) {
+                            if ((x[j] | (y[j] << 8)) == z.scan2) { z.mode = kCmp; z.l = 0; } // may be longer than best: compare in full
+                            else {
+                                const uint32_t nq = e[j] - 1;
+                                z.steps++;
+                                if (z.steps == chainQ) { z.snap_best = z.best; z.snap_q = z.bestq; }
+                                const bool stop = z.steps == chainF || (int)nq <= z.limit_q; // best < nice while walking
+                                z.q = nq;
+                                z.mode = stop ? kDone : kWalk;
+                            }
+                        }
+                    }
                 }
             }
         }
