@@ -40,43 +40,69 @@ size_t lz_parallel_workspace_bytes(uint32_t batch) { return (size_t)batch * kChu
 bool lz_parallel_available() { return true; }
 
 // ------------------------------------------------------------------------------------------------- K1
+// One wave per chunk.  The input is consumed in 256-byte blocks: each lane fetches one dword of the *next* block
+// while the current one is processed (global latency hidden), blocks are staged in a small LDS buffer so that the
+// three bytes of a position are aligned byte reads.  head[] (LDS, 64 KiB) holds p+1 of the latest position of each
+// hash, 0 = empty.
 __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__restrict__ links)
 {
     __shared__ uint16_t head[kHashSize];
+    __shared__ uint32_t stage[2][66]; // two 256-byte blocks (+8 bytes of the following block)
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *lk = links + (size_t)c * kChunkMax;
-    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0; // head[] holds p+1, 0 = empty
-    __syncthreads();
+    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0; // positions 0 .. n-3 carry a hash
-    volatile uint16_t *vhead = head; // the claim/read-back below must really go through LDS
-    for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        const bool live = p < npos;
-        uint32_t h = 0, old = kNoLink;
-        if (live) { h = hash3(src[p], src[p + 1], src[p + 2]); old = vhead[h]; }
-        uint32_t link = old;
-        bool last = live; // the highest lane of a hash group leaves its position in head[]
-        // claim the slot (LDS executes one wave's operations in order; when several lanes hit the same slot one of them
-        // lands), then read it back: a lane that does not see itself shares its hash with another lane of this step
-        if (live) vhead[h] = (uint16_t)(p + 1);
-        const uint32_t seen = live ? (uint32_t)vhead[h] : p + 1;
-        unsigned long long clash = __ballot(live && seen != p + 1);
-        while (clash) {
-            const int f = __ffsll((long long)clash) - 1;
-            const uint32_t h0 = __shfl(h, f);
-            const unsigned long long grp = __ballot(live && h == h0);
-            if (live && h == h0) {
-                const unsigned long long below = grp & ((1ull << lane) - 1);
-                if (below) link = p0 + (63 - __clzll((long long)below)) + 1; // nearest lower lane with the same hash
-                last = (grp >> lane) == 1ull;
+    volatile uint16_t *vhead = head;          // the claim/read-back below must really go through LDS
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    auto fetch = [&](uint32_t blk) -> uint32_t { // dword `lane` of block blk, zero padded past n
+        const uint32_t a = blk * 256 + lane * 4;
+        if (a + 4 <= n && aligned) return *reinterpret_cast<const uint32_t *>(src + a);
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; k++) if (a + k < n) v |= (uint32_t)src[a + k] << (8 * k);
+        return v;
+    };
+    const uint32_t nblk = (npos + 255) / 256;
+    uint32_t cur = nblk ? fetch(0) : 0, nxt = nblk > 1 || n > 256 ? fetch(1) : 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t *st = stage[b & 1];
+        st[lane] = cur;
+        if (lane < 2) st[64 + lane] = __shfl(nxt, lane); // first 8 bytes of the next block
+        const uint32_t nn = (b + 2) * 256 < n + 256 ? fetch(b + 2) : 0; // prefetch two blocks ahead
+        const uint8_t *s8 = reinterpret_cast<const uint8_t *>(st);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll 1
+        for (uint32_t sb = 0; sb < 4; sb++) {
+            const uint32_t o = sb * 64 + lane, p = b * 256 + o, p0 = b * 256 + sb * 64;
+            if (p0 >= npos) break;
+            const bool live = p < npos;
+            uint32_t h = 0, old = kNoLink;
+            if (live) { h = hash3(s8[o], s8[o + 1], s8[o + 2]); old = vhead[h]; }
+            uint32_t link = old;
+            bool last = live; // the highest lane of a hash group leaves its position in head[]
+            // claim the slot (LDS executes one wave's operations in order; when several lanes hit the same slot one of
+            // them lands), then read it back: a lane that does not see itself shares its hash with another lane
+            if (live) vhead[h] = (uint16_t)(p + 1);
+            const uint32_t seen = live ? (uint32_t)vhead[h] : p + 1;
+            unsigned long long clash = __ballot(live && seen != p + 1);
+            while (clash) {
+                const int f = __ffsll((long long)clash) - 1;
+                const uint32_t h0 = __shfl(h, f);
+                const unsigned long long grp = __ballot(live && h == h0);
+                if (live && h == h0) {
+                    const unsigned long long below = grp & ((1ull << lane) - 1);
+                    if (below) link = p0 + (63 - __clzll((long long)below)) + 1; // nearest lower lane with the same hash
+                    last = (grp >> lane) == 1ull;
+                }
+                clash &= ~grp;
             }
-            clash &= ~grp;
+            if (live && last) vhead[h] = (uint16_t)(p + 1);
+            if (live) lk[p] = (uint16_t)link;
         }
-        if (live && last) vhead[h] = (uint16_t)(p + 1);
-        if (live) lk[p] = (uint16_t)link;
+        cur = nxt; nxt = nn;
     }
     for (uint32_t p = npos + lane; p < n; p += 64) lk[p] = (uint16_t)kNoLink;
 }
@@ -328,6 +354,10 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
 }
 
 // ------------------------------------------------------------------------------------------------- K3
+// One lane per chunk.  Measured alternatives (MI355X, 1 GiB = 16384 chunks): a wave-per-chunk scalar automaton over a
+// register window of records is bound by the single scalar unit per CU (59 ms); lane-per-chunk with per-lane LDS
+// windows refilled by divergent 16-byte loads is bound by those refills (187 ms); this plain form costs 85 ms at
+// 1 GiB (one wave per CU, latency-bound) and scales with the number of resident waves at larger inputs.
 __global__ void __launch_bounds__(64) parse_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
                                                    ChunkMeta *meta)
 {
