@@ -1,0 +1,95 @@
+"""GPU parity tests for the inflate path (through the C ABI): bytes identical to the input / to the CPU oracle,
+error class and message identical to the reference's verdicts stored in tests/golden/inflate_cases.json."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cases, corpus_py as CP, oracle_py as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zlib_amd
+    e = zlib_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def oracle_stream(data, level, chunk=65536):
+    """raw body (no zlib header) of the mode-B stream + segment offsets, from the CPU oracle"""
+    n = len(data)
+    nchunks = max(1, (n + chunk - 1) // chunk)
+    segs = [O.deflate_chunk(data[k * chunk:(k + 1) * chunk], level, k == nchunks - 1) for k in range(nchunks)]
+    offs = np.zeros(nchunks + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in segs])
+    return b"".join(segs), offs
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_inflate_oracle_streams(eng, level):
+    """Streams produced by the CPU oracle (= the reference's bytes): stored, static and dynamic blocks, multi-block
+    chunks (high-entropy data), ragged tail."""
+    for kind, n in (("mix", 300000), ("rand", 70000), ("text", 65536 * 3), ("zeros", 100000), ("ab", 40000), ("text", 5), ("rand", 0)):
+        data = cases.make(kind, n, 21)
+        body, offs = oracle_stream(data, level)
+        out = eng.inflate_host(body, offs, out_len=max(len(data), 1))
+        assert out == data, (kind, n, level)
+        assert eng.last_inflate.adler32 == O.adler32(data)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_roundtrip_engine_to_engine(eng, level):
+    data = CP.chunks(CP.KIND_SILESIA, 200, 48).tobytes()[: 48 * 65536 - 777]
+    z, offs = eng.deflate_host(data, level, want_offsets=True)
+    out = eng.inflate_host(z, offs, out_len=len(data))
+    assert out == data
+    assert eng.last_inflate.adler32 == int.from_bytes(z[-4:], "big")
+    # and the CPU oracle accepts the engine's stream
+    rc, ref_out, used, msg = O.inflate_zlib(z, len(data))
+    assert rc == 1 and ref_out == data and used == len(z)
+
+
+def test_smaller_chunk_size_roundtrip(eng):
+    data = cases.make("mix", 200000, 5)
+    for cs in (4096, 32768):
+        z, offs = eng.deflate_host(data, 6, chunk_size=cs, want_offsets=True)
+        assert eng.inflate_host(z, offs, chunk_size=cs, out_len=len(data)) == data
+
+
+def test_corrupt_streams_match_reference_verdict(eng, golden):
+    import zlib_amd
+    g = golden("inflate_cases.json")
+    seen = set()
+    for stream_hex, cap, rc, msg, sha_out, len_out in g["rows"]:
+        raw = bytes.fromhex(stream_hex)
+        offs = np.array([0, len(raw)], dtype=np.uint64)
+        if rc == 1:
+            out = eng.inflate_host(raw, offs, chunk_size=min(cap, 65536), out_len=cap)
+            assert [len(out), hashlib.sha256(out).hexdigest()[:16]] == [len_out, sha_out]
+        else:
+            with pytest.raises(zlib_amd.EngineError) as ei:
+                eng.inflate_host(raw, offs, chunk_size=min(cap, 65536), out_len=cap)
+            if rc == -3:
+                assert ei.value.code == -3 and msg in str(ei.value), (msg, str(ei.value))
+                seen.add(msg)
+            else:
+                assert ei.value.code in (-3, -5)
+    assert len(seen) >= 6
+
+
+def test_segment_rules(eng):
+    import zlib_amd
+    data = cases.make("text", 65536 * 2, 3)
+    body, offs = oracle_stream(data, 6)
+    # wrong split point
+    bad = offs.copy(); bad[1] += 1
+    with pytest.raises(zlib_amd.EngineError):
+        eng.inflate_host(body, bad, out_len=len(data))
+    # last segment without a final block
+    segs = [O.deflate_chunk(data[:65536], 6, False), O.deflate_chunk(data[65536:], 6, False)]
+    o2 = np.array([0, len(segs[0]), len(segs[0]) + len(segs[1])], dtype=np.uint64)
+    with pytest.raises(zlib_amd.EngineError):
+        eng.inflate_host(b"".join(segs), o2, out_len=len(data))

@@ -50,6 +50,8 @@ struct zgpu_engine {
     uint64_t stage_in_cap = 0, stage_out_cap = 0;
     // inflate scratch
     void *inf_status = nullptr; uint64_t inf_status_cap = 0;
+    zgpu::ChunkMeta *inf_meta = nullptr; uint32_t inf_meta_cap = 0;
+    uint64_t *inf_offs = nullptr; uint64_t inf_offs_cap = 0;
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -291,7 +293,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
-    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status);
+    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     hipStreamDestroy(e->stream);
     delete e;
@@ -457,6 +459,37 @@ int zgpu_corpus_fill_device(zgpu_engine *e, uint32_t kind, uint64_t seed, uint64
 
 // hooks used by zgpu_lz_parallel.hip to time its sub-stages with the engine's event pool
 namespace zgpu {
+void *engine_scratch(zgpu_engine *e, size_t bytes)
+{
+    if (bytes > e->inf_status_cap) {
+        hipFree(e->inf_status); e->inf_status = nullptr; e->inf_status_cap = 0;
+        if (hipMalloc(&e->inf_status, bytes) != hipSuccess) return nullptr;
+        e->inf_status_cap = bytes;
+    }
+    return e->inf_status;
+}
+void *engine_run_state(zgpu_engine *e) { return e->run; }
+ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch)
+{
+    if (batch > e->inf_meta_cap) {
+        hipFree(e->inf_meta); e->inf_meta = nullptr; e->inf_meta_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&e->inf_meta), (size_t)batch * sizeof(ChunkMeta)) != hipSuccess) return nullptr;
+        e->inf_meta_cap = batch;
+    }
+    return e->inf_meta;
+}
+uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n)
+{
+    if (n > e->inf_offs_cap) {
+        hipFree(e->inf_offs); e->inf_offs = nullptr; e->inf_offs_cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&e->inf_offs), n * sizeof(uint64_t)) != hipSuccess) return nullptr;
+        e->inf_offs_cap = n;
+    }
+    return e->inf_offs;
+}
+int engine_device(zgpu_engine *e) { return e->device; }
+void engine_collect(zgpu_engine *e) { collect_spans(e); }
+int engine_fail(zgpu_engine *e, int code, const char *msg) { return fail(e, code, msg); }
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a)
 {
     zgpu_engine *e = static_cast<zgpu_engine *>(eng);

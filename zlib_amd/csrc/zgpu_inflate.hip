@@ -1,13 +1,426 @@
-// zgpu_inflate.hip -- placeholder until the decode kernel lands.
+// zgpu_inflate.hip -- decode path: one wave per chunk segment.
+//
+// Restates (file:line under /root/reference):
+//   block header / stored / dynamic-table states of inflate()   qcsrc/inflate.c:773-949
+//   code-length validation of inflate_table                     qcsrc/inftrees.c:106-138
+//   symbol decode + match copy (inflate_fast and the slow path) qcsrc/inffast.c:67-302, qcsrc/inflate.c:950-1076
+//   length / distance bases and extra bits                      qcsrc/inftrees.c:60-73
+// The reference decodes through 2-level tables of `code` structs; only the produced bytes and the error class are
+// observable, so the table layout here is the engine's own: a 10-bit (literal/length) and a 9-bit (distance) direct
+// table in LDS, codes longer than that resolved by a canonical first-code walk.
+//
+// Work split: the bit reader and symbol decode are wave-uniform (every lane computes the same values: the decode of one
+// deflate stream is sequential); lanes cooperate on table fill, input staging (1 KiB per refill, 16 bytes per lane),
+// match copies (64 bytes per step) and the final store of the chunk (16 bytes per lane).  The whole output chunk
+// (<= 64 KiB) lives in LDS while it is decoded, so back-references never touch global memory.
 #include "zgpu_common.h"
 #include "../../include/zamd_gpu.h"
+#include <cstdio>
+
 struct zgpu_engine;
+
 namespace zgpu {
-int inflate_run(zgpu_engine *, const uint8_t *, uint64_t, const uint64_t *, uint64_t, uint32_t, uint8_t *, uint64_t, zgpu_inflate_result *, hipStream_t) { return ZGPU_STREAM_ERROR; }
+
+int fail_hip(zgpu_engine *e, hipError_t err, const char *what, const char *file, int line);
+void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
+void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
+void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
+void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
+
+enum InfMsg : uint32_t {
+    kMsgNone = 0, kMsgBlockType, kMsgStoredLen, kMsgTooMany, kMsgCodeLens, kMsgRepeat, kMsgLitLens, kMsgDists, kMsgLitCode, kMsgDistCode,
+    kMsgTooFar, kMsgTruncated, kMsgOutput, kMsgTrailing, kMsgShort, kMsgCount
+};
+static const char *const kInfMessages[kMsgCount] = {
+    "", "invalid block type", "invalid stored block lengths", "too many length or distance symbols", "invalid code lengths set",
+    "invalid bit length repeat", "invalid literal/lengths set", "invalid distances set", "invalid literal/length code", "invalid distance code",
+    "invalid distance too far back", "segment ends inside a block", "segment decodes to more than chunk_size bytes",
+    "segment holds data after its last block", "segment decodes to fewer than chunk_size bytes"};
+
+struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t pad; };
+
+constexpr uint32_t kLBits = 10, kDBits = 9, kStageDwords = 512;
+
+struct InflateLds {
+    uint8_t out[kChunkMax];
+    uint32_t ltab[1 << kLBits]; // sym << 8 | len, 0 = longer than kLBits (or unassigned)
+    uint32_t dtab[1 << kDBits];
+    uint32_t stage[kStageDwords]; // ring of input dwords
+    uint16_t lens[320];
+    uint16_t lsym[288], dsym[32]; // symbols sorted by (length, symbol) for the long-code walk
+    uint16_t lcount[16], dcount[16];
+};
+
+// Wave-uniform bit reader over a ring of input dwords in LDS.
+struct BitSrc {
+    const uint32_t *g32; // aligned global dwords
+    uint64_t gdwords;    // dwords that may be read from g32 (bounds the whole input buffer)
+    uint64_t d0;         // index of the first dword of the segment inside g32
+    uint32_t filled;     // dwords of the segment staged so far
+    uint32_t rd;         // dwords consumed into hold
+    uint64_t hold;
+    uint32_t bits;
+    uint32_t seg_bits;   // size of the segment in bits (from its first dword, including the leading byte offset)
+};
+
+__device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
+{
+    // keep at least 256 dwords ahead of the reader; each call loads 256 dwords (16 bytes per lane)
+    while (b.filled - b.rd < 256) {
+        const uint64_t i = b.d0 + b.filled + lane * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i + k < b.gdwords) ? b.g32[i + k] : 0u;
+        const uint32_t s = (b.filled + lane * 4) & (kStageDwords - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) stage[s + k] = v[k];
+        b.filled += 256;
+    }
+}
+__device__ inline void refill(BitSrc &b, const uint32_t *stage)
+{
+    if (b.bits <= 32) { b.hold |= (uint64_t)stage[b.rd & (kStageDwords - 1)] << b.bits; b.rd++; b.bits += 32; }
+}
+__device__ inline uint32_t peek(const BitSrc &b, uint32_t n) { return (uint32_t)b.hold & ((1u << n) - 1); }
+__device__ inline void drop(BitSrc &b, uint32_t n) { b.hold >>= n; b.bits -= n; }
+__device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b.bits; }
+
+// Build one decoding table from code lengths lens[0..n).  kind: 0 code-length code, 1 literal/length, 2 distance.
+// Acceptance rules of inflate_table (inftrees.c:106-138).  Returns 0 ok, 1 rejected.  Lane 0 does the serial part.
+__device__ uint32_t build_table(const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab, uint16_t *sorted, uint16_t *count,
+                                uint32_t lane)
+{
+    __shared__ uint32_t sh_rc;
+    __shared__ uint16_t code_of[320];
+    for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
+    if (lane == 0) {
+        uint32_t cnt[16], offs[16], next[16];
+        for (int l = 0; l < 16; l++) cnt[l] = 0;
+        for (uint32_t s = 0; s < n; s++) cnt[lens[s]]++;
+        int maxl = 15; while (maxl >= 1 && cnt[maxl] == 0) maxl--;
+        uint32_t rc = 0;
+        if (maxl > 0) {
+            int left = 1;
+            for (int l = 1; l <= 15; l++) { left <<= 1; left -= (int)cnt[l]; if (left < 0) { rc = 1; break; } }
+            if (!rc && left > 0 && (kind == 0 || maxl != 1)) rc = 1; // incomplete set
+        }
+        uint32_t c = 0; offs[1] = 0; cnt[0] = 0;
+        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; next[l] = c; if (l < 15) offs[l + 1] = offs[l] + cnt[l]; }
+        for (int l = 0; l < 16; l++) count[l] = (uint16_t)cnt[l];
+        if (!rc) for (uint32_t s = 0; s < n; s++) { const uint32_t l = lens[s]; if (l) { code_of[s] = (uint16_t)next[l]++; sorted[offs[l]++] = (uint16_t)s; } }
+        sh_rc = rc;
+    }
+    __syncthreads();
+    if (sh_rc) return 1;
+    for (uint32_t s = lane; s < n; s += 64) {
+        const uint32_t l = lens[s];
+        if (l && l <= tbits) {
+            const uint32_t rev = __brev((uint32_t)code_of[s]) >> (32 - l);
+            for (uint32_t i = rev; i < (1u << tbits); i += 1u << l) tab[i] = (s << 8) | l;
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
+// decode one symbol; returns the symbol, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code)
+__device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
+{
+    const uint32_t e = tab[peek(b, tbits)];
+    if (e) { drop(b, e & 255); return e >> 8; }
+    // canonical walk (first-code method) for codes longer than the table, and for unassigned patterns
+    int code = 0, first = 0, index = 0;
+    uint64_t h = b.hold;
+    for (uint32_t l = 1; l <= 15; l++) {
+        code |= (int)(h & 1); h >>= 1;
+        const int c = count[l];
+        if (code - c < first) { drop(b, l); return sorted[index + (code - first)]; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return 0xFFFFu;
+}
+
+__constant__ const uint16_t kLBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ const uint8_t kLExt[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ const uint16_t kDBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ const uint8_t kDExt[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
+                                                     uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size,
+                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status)
+{
+    extern __shared__ uint8_t lds_raw[];
+    InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t gc = chunk0 + c, seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
+    const bool must_be_final = gc == last_chunk;
+    uint32_t err = kMsgNone;
+
+    BitSrc b;
+    const uint64_t in_addr = reinterpret_cast<uint64_t>(in);
+    const uint64_t abs_lo = in_addr + seg_lo, abs_al = abs_lo & ~3ull;
+    b.g32 = reinterpret_cast<const uint32_t *>(abs_al);
+    b.gdwords = (in_addr + in_bytes - abs_al + 3) >> 2; // reads past the input buffer are replaced by zeros, see stage_fill
+    // the dword holding the last input bytes may extend past the buffer by up to 3 bytes inside the same aligned dword
+    b.d0 = 0; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+    const uint32_t lead = (uint32_t)(abs_lo - abs_al);
+    b.seg_bits = (uint32_t)(seg_hi - seg_lo + lead) * 8;
+    stage_fill(b, L.stage, lane);
+    __syncthreads();
+    refill(b, L.stage); refill(b, L.stage);
+    drop(b, lead * 8);
+
+    uint32_t o = 0; // bytes produced
+    bool last = false, seen_final = false;
+    while (!err && !last) {
+        if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
+        stage_fill(b, L.stage, lane); __syncthreads();
+        refill(b, L.stage);
+        const uint32_t hdr = peek(b, 3); drop(b, 3);
+        last = hdr & 1; seen_final = seen_final || last;
+        const uint32_t type = hdr >> 1;
+        if (type == 3) { err = kMsgBlockType; break; }
+        if (type == 0) {
+            drop(b, b.bits & 7);
+            refill(b, L.stage);
+            const uint32_t len = peek(b, 16); drop(b, 16);
+            refill(b, L.stage);
+            const uint32_t nlen = peek(b, 16); drop(b, 16);
+            if (len != (nlen ^ 0xFFFFu)) { err = kMsgStoredLen; break; }
+            const uint32_t bytepos = consumed_bits(b) >> 3; // from the reader's current origin (dword b.d0 of the segment)
+            if ((uint64_t)bytepos + len > (b.seg_bits >> 3)) { err = kMsgTruncated; break; }
+            if (o + len > chunk_size) { err = kMsgOutput; break; }
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(b.g32 + b.d0) + bytepos;
+            for (uint32_t i = lane; i < len; i += 64) L.out[o + i] = src[i];
+            o += len;
+            // reposition the reader right after the stored bytes: new origin = the dword holding that byte
+            const uint32_t np = bytepos + len;
+            b.d0 += np >> 2; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+            b.seg_bits -= (np & ~3u) * 8; // seg_bits stays relative to the origin
+            __syncthreads();
+            stage_fill(b, L.stage, lane); __syncthreads();
+            refill(b, L.stage); refill(b, L.stage);
+            drop(b, (np & 3) * 8);
+            continue;
+        }
+        // ---- tables ----
+        if (type == 1) {
+            for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+            __syncthreads();
+            build_table(L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
+            __syncthreads();
+            for (uint32_t s = lane; s < 32; s += 64) L.lens[s] = 5;
+            __syncthreads();
+            build_table(L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
+        } else {
+            refill(b, L.stage);
+            const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
+            const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
+            const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
+            if (nlen > 286 || ndist > 30) { err = kMsgTooMany; break; }
+            __syncthreads();
+            for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+            __syncthreads();
+            for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
+            __syncthreads();
+            // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
+            if (build_table(L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
+            __syncthreads();
+            for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+            __syncthreads();
+            uint32_t have = 0, prev = 0;
+            while (have < nlen + ndist) {
+                stage_fill(b, L.stage, lane);
+                refill(b, L.stage);
+                const uint32_t s = decode_sym(b, L.dtab, 7, L.dsym, L.dcount);
+                if (s == 0xFFFFu) { err = kMsgCodeLens; break; }
+                if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
+                uint32_t rep, val = 0;
+                refill(b, L.stage);
+                if (s == 16) { if (have == 0) { err = kMsgRepeat; break; } val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
+                else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
+                else { rep = 11 + peek(b, 7); drop(b, 7); }
+                if (have + rep > nlen + ndist) { err = kMsgRepeat; break; }
+                if (lane < rep) L.lens[have + lane] = (uint16_t)val;
+                if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
+                if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
+                prev = val; have += rep;
+            }
+            if (err) break;
+            __syncthreads();
+            if (build_table(L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
+            __syncthreads();
+            if (build_table(L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
+        }
+        __syncthreads();
+        // ---- symbols ----
+        for (;;) {
+            stage_fill(b, L.stage, lane);
+            refill(b, L.stage);
+            if (consumed_bits(b) > b.seg_bits) { err = kMsgTruncated; break; }
+            uint32_t s = decode_sym(b, L.ltab, kLBits, L.lsym, L.lcount);
+            if (s == 0xFFFFu || s > 285) { err = kMsgLitCode; break; }
+            if (s < 256) {
+                if (o >= chunk_size) { err = kMsgOutput; break; }
+                if (lane == 0) L.out[o] = (uint8_t)s;
+                o++;
+                continue;
+            }
+            if (s == 256) break;
+            s -= 257;
+            const uint32_t len = kLBase[s] + peek(b, kLExt[s]); drop(b, kLExt[s]);
+            refill(b, L.stage);
+            const uint32_t d = decode_sym(b, L.dtab, kDBits, L.dsym, L.dcount);
+            if (d == 0xFFFFu || d > 29) { err = kMsgDistCode; break; }
+            const uint32_t dist = kDBase[d] + peek(b, kDExt[d]); drop(b, kDExt[d]);
+            if (dist > o) { err = kMsgTooFar; break; }
+            if (o + len > chunk_size) { err = kMsgOutput; break; }
+            // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (dist >= len || dist >= 64) {
+                for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
+                    const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
+                    uint8_t v = 0;
+                    if (lane < span && i < len) v = L.out[o - dist + i];
+                    if (lane < span && i < len) L.out[o + i] = v;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+            } else {
+                const uint32_t recip = 0xFFFFFFFFu / dist + 1;
+                for (uint32_t i = lane; i < len; i += 64) {
+                    const uint32_t qd = __umulhi(i, recip), r = i - qd * dist;
+                    L.out[o + i] = L.out[o - dist + r];
+                }
+            }
+            o += len;
+        }
+    }
+    if (!err) {
+        const uint32_t used = consumed_bits(b);
+        if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
+        else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
+        else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
+        else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
+        else if (!must_be_final && o != chunk_size) err = kMsgShort;      // output placement assumes full chunks
+    }
+    __syncthreads();
+    // store the chunk
+    uint8_t *dst = out + gc * (uint64_t)chunk_size;
+    const bool fits = gc * (uint64_t)chunk_size + o <= out_cap;
+    if (!err && fits) {
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+            const uint4 *s128 = reinterpret_cast<const uint4 *>(L.out);
+            for (uint32_t i = lane; i < (o >> 4); i += 64) reinterpret_cast<uint4 *>(dst)[i] = s128[i];
+            for (uint32_t i = (o & ~15u) + lane; i < o; i += 64) dst[i] = L.out[i];
+        } else {
+            for (uint32_t i = lane; i < o; i += 64) dst[i] = L.out[i];
+        }
+    }
+    if (lane == 0) {
+        status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
+        status[c].msg = err; status[c].out_bytes = err ? 0 : o;
+    }
+}
+
+// first failing chunk + total bytes (one workgroup; chunk order matters for "first")
+__global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *st, uint32_t nchunks, uint64_t chunk0, uint32_t chunk_size, uint64_t *acc)
+{
+    // acc[0] total bytes, acc[1] first bad chunk (+1, 0 = none), acc[2] its code, acc[3] its msg, acc[4] "short chunk before the end" flag
+    __shared__ unsigned long long bad_min;
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0) { bad_min = ~0ull; total = 0; }
+    __syncthreads();
+    unsigned long long t = 0, bad = ~0ull;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) { t += st[i].out_bytes; if (st[i].code != 0 && bad == ~0ull) bad = chunk0 + i; }
+    atomicAdd(&total, t);
+    atomicMin(&bad_min, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc[0] += total;
+        if (acc[1] == 0 && bad_min != ~0ull) { acc[1] = bad_min + 1; acc[2] = (uint64_t)(int64_t)st[bad_min - chunk0].code; acc[3] = st[bad_min - chunk0].msg; }
+    }
+}
+
+int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
+
 } // namespace zgpu
+
+using namespace zgpu;
+
+// engine internals needed here (defined in zgpu_engine.hip)
+namespace zgpu {
+void *engine_scratch(zgpu_engine *e, size_t bytes);          // grow-only device scratch
+void *engine_run_state(zgpu_engine *e);
+ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch);
+uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
+int engine_device(zgpu_engine *e);
+void engine_collect(zgpu_engine *e);
+int engine_fail(zgpu_engine *e, int code, const char *msg);
+struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow; };
+
+int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
+{
+    if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || chunk_size == 0 || chunk_size > kChunkMax)
+        return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
+    ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
+    const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
+    InfStatus *status = static_cast<InfStatus *>(engine_scratch(e, (size_t)batch * sizeof(InfStatus) + 64));
+    if (!status) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
+    uint64_t *acc = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(status) + (((size_t)batch * sizeof(InfStatus) + 15) & ~(size_t)15));
+    ChunkMeta *meta = engine_meta(e, batch);
+    if (!meta) return engine_fail(e, ZGPU_MEM_ERROR, "inflate meta");
+    uint64_t *oscr = engine_offsets_scratch(e, nchunks + 1);
+    if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
+    ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(uint64_t), st));
+    RunStateHostI rs{}; rs.adler_a = 1;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    static bool opt_in = false;
+    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds)); opt_in = true; }
+    hipEvent_t ev{};
+    prof_span_begin(e, st, &ev);
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(64), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size, d_out,
+                           out_cap, status);
+        hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc);
+        ZGPU_HIP_CHECK(hipGetLastError());
+    }
+    prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
+    uint64_t h[5];
+    ZGPU_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    res->out_bytes = h[0]; res->first_bad_chunk = h[1] ? (int32_t)(h[1] - 1) : -1; res->error_code = (int32_t)(int64_t)h[2]; res->error_msg = (uint32_t)h[3];
+    res->adler32 = 1;
+    if (h[1]) { engine_collect(e); return engine_fail(e, res->error_code, kInfMessages[res->error_msg < kMsgCount ? res->error_msg : 0]); }
+    // every chunk but the last must be full, or the output would have holes
+    if (nchunks > 1 && h[0] <= (nchunks - 1) * (uint64_t)chunk_size - 1 + 0 && h[0] < (nchunks - 1) * (uint64_t)chunk_size) {
+        engine_collect(e);
+        res->error_code = ZGPU_DATA_ERROR; res->error_msg = kMsgOutput;
+        return engine_fail(e, ZGPU_DATA_ERROR, "a segment other than the last decoded to fewer than chunk_size bytes");
+    }
+    // Adler-32 of the produced bytes (same kernels as the compress side)
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = chunk_size; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
+        ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
+        launch_adler(g, meta, st);
+        launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st);
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, engine_run_state(e), sizeof rs, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    engine_collect(e);
+    res->adler32 = rs.adler_a | (rs.adler_b << 16);
+    return ZGPU_OK;
+}
+} // namespace zgpu
+
 extern "C" {
 #pragma GCC visibility push(default)
+const char *zgpu_inflate_message(uint32_t index) { return index < kMsgCount ? kInfMessages[index] : ""; }
 int zgpu_inflate_find_chunks_host(zgpu_engine *, const void *, uint64_t, uint32_t, uint64_t *, uint64_t, uint64_t *) { return ZGPU_STREAM_ERROR; }
-const char *zgpu_inflate_message(uint32_t) { return ""; }
 #pragma GCC visibility pop
 }
