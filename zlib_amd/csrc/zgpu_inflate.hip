@@ -49,6 +49,9 @@ struct InflateLds {
     uint16_t lens[320];
     uint16_t lsym[288], dsym[32]; // symbols sorted by (length, symbol) for the long-code walk
     uint16_t lcount[16], dcount[16];
+    uint16_t code_of[320]; // canonical code of each symbol while a table is being built
+    uint16_t work_offs[16], work_next[16];
+    uint32_t build_rc;
 };
 
 // Wave-uniform bit reader over a ring of input dwords in LDS.
@@ -86,15 +89,15 @@ __device__ inline void drop(BitSrc &b, uint32_t n) { b.hold >>= n; b.bits -= n; 
 __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b.bits; }
 
 // Build one decoding table from code lengths lens[0..n).  kind: 0 code-length code, 1 literal/length, 2 distance.
-// Acceptance rules of inflate_table (inftrees.c:106-138).  Returns 0 ok, 1 rejected.  Lane 0 does the serial part.
-__device__ uint32_t build_table(const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab, uint16_t *sorted, uint16_t *count,
-                                uint32_t lane)
+// Acceptance rules of inflate_table (inftrees.c:106-138).  Returns 0 ok, 1 rejected.  Lane 0 does the serial part
+// (its small work arrays live in LDS: dynamically indexed private arrays would go to scratch memory).
+__device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
+                                             uint16_t *sorted, uint16_t *count, uint32_t lane)
 {
-    __shared__ uint32_t sh_rc;
-    __shared__ uint16_t code_of[320];
+    __syncthreads();
     for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
     if (lane == 0) {
-        uint32_t cnt[16], offs[16], next[16];
+        uint16_t *cnt = count, *offs = L.work_offs, *next = L.work_next;
         for (int l = 0; l < 16; l++) cnt[l] = 0;
         for (uint32_t s = 0; s < n; s++) cnt[lens[s]]++;
         int maxl = 15; while (maxl >= 1 && cnt[maxl] == 0) maxl--;
@@ -105,26 +108,27 @@ __device__ uint32_t build_table(const uint16_t *lens, uint32_t n, uint32_t kind,
             if (!rc && left > 0 && (kind == 0 || maxl != 1)) rc = 1; // incomplete set
         }
         uint32_t c = 0; offs[1] = 0; cnt[0] = 0;
-        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; next[l] = c; if (l < 15) offs[l + 1] = offs[l] + cnt[l]; }
-        for (int l = 0; l < 16; l++) count[l] = (uint16_t)cnt[l];
-        if (!rc) for (uint32_t s = 0; s < n; s++) { const uint32_t l = lens[s]; if (l) { code_of[s] = (uint16_t)next[l]++; sorted[offs[l]++] = (uint16_t)s; } }
-        sh_rc = rc;
+        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; next[l] = (uint16_t)c; if (l < 15) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); }
+        if (!rc) for (uint32_t s = 0; s < n; s++) { const uint32_t l = lens[s]; if (l) { L.code_of[s] = next[l]++; sorted[offs[l]++] = (uint16_t)s; } }
+        L.build_rc = rc;
     }
     __syncthreads();
-    if (sh_rc) return 1;
-    for (uint32_t s = lane; s < n; s += 64) {
-        const uint32_t l = lens[s];
-        if (l && l <= tbits) {
-            const uint32_t rev = __brev((uint32_t)code_of[s]) >> (32 - l);
-            for (uint32_t i = rev; i < (1u << tbits); i += 1u << l) tab[i] = (s << 8) | l;
+    const uint32_t rc = L.build_rc;
+    if (rc == 0) {
+        for (uint32_t s = lane; s < n; s += 64) {
+            const uint32_t l = lens[s];
+            if (l && l <= tbits) {
+                const uint32_t rev = __brev((uint32_t)L.code_of[s]) >> (32 - l);
+                for (uint32_t i = rev; i < (1u << tbits); i += 1u << l) tab[i] = (s << 8) | l;
+            }
         }
     }
     __syncthreads();
-    return 0;
+    return rc;
 }
 
 // decode one symbol; returns the symbol, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code)
-__device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
+__device__ __noinline__ uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
 {
     const uint32_t e = tab[peek(b, tbits)];
     if (e) { drop(b, e & 255); return e >> 8; }
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
                                                      uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size,
                                                      uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status)
 {
-    extern __shared__ uint8_t lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     if (c >= nchunks) return;
@@ -209,11 +213,11 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         if (type == 1) {
             for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
             __syncthreads();
-            build_table(L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
+            build_table(L, L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
             __syncthreads();
             for (uint32_t s = lane; s < 32; s += 64) L.lens[s] = 5;
             __syncthreads();
-            build_table(L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
+            build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
         } else {
             refill(b, L.stage);
             const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
             __syncthreads();
             // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
-            if (build_table(L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
+            if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
             __syncthreads();
             for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
             __syncthreads();
@@ -250,9 +254,13 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             }
             if (err) break;
             __syncthreads();
-            if (build_table(L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
+            asm volatile("" ::: "memory");
+#ifdef ZGPU_INF_DEBUG
+            if (lane == 0 && c == 0) { printf("nlen %u ndist %u ncode %u have %u\n", nlen, ndist, ncode, have); for (uint32_t i = 0; i < nlen + ndist; i++) printf("%u ", (unsigned)L.lens[i]); printf("\n"); }
+#endif
+            if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
             __syncthreads();
-            if (build_table(L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
+            if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
         }
         __syncthreads();
         // ---- symbols ----
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             } else {
                 const uint32_t recip = 0xFFFFFFFFu / dist + 1;
                 for (uint32_t i = lane; i < len; i += 64) {
-                    const uint32_t qd = __umulhi(i, recip), r = i - qd * dist;
+                    const uint32_t qd = dist == 1 ? i : __umulhi(i, recip), r = i - qd * dist; // recip overflows for dist 1
                     L.out[o + i] = L.out[o - dist + r];
                 }
             }
@@ -305,6 +313,9 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
         else if (!must_be_final && o != chunk_size) err = kMsgShort;      // output placement assumes full chunks
     }
+#ifdef ZGPU_INF_DEBUG2
+    if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
+#endif
     __syncthreads();
     // store the chunk
     uint8_t *dst = out + gc * (uint64_t)chunk_size;
