@@ -109,8 +109,10 @@ int zgpu_deflate_segments_host(zgpu_engine *e, const void *in, const uint64_t *s
 
 /* ---- inflate ---- */
 /* Segment k = d_in[offsets[k] .. offsets[k+1]) is a raw-deflate segment that decodes to at most
- * chunk_size bytes, written at d_out + k*chunk_size.  The last segment must end with a final block;
- * the others end with a stored empty block (flush marker). */
+ * chunk_size bytes, written at d_out + k*chunk_size (every segment but the last must decode to exactly
+ * chunk_size bytes).  chunk_size == 0 selects "compact" mode: segments of any size up to 65536 bytes are
+ * decoded and their outputs concatenated (streams that were flushed in the middle of a chunk).  The last
+ * segment must end with a final block; the others end with a stored empty block (flush marker). */
 int zgpu_inflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_chunk_offsets,
                         uint64_t nchunks, uint32_t chunk_size, void *d_out, uint64_t out_cap,
                         zgpu_inflate_result *res, void *hip_stream);
@@ -122,6 +124,9 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
  * header).  Returns ZGPU_OK and *nchunks, or ZGPU_DATA_ERROR when no consistent split exists. */
 int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size,
                                   uint64_t *offsets, uint64_t max_chunks, uint64_t *nchunks);
+/* The same search, delivering the decoded bytes: raw deflate body in (no zlib header / trailer), bytes out. */
+int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap,
+                             zgpu_inflate_result *res);
 const char *zgpu_inflate_message(uint32_t index);
 
 /* ---- checksums (qcsrc/adler32.c:57-149) ---- */

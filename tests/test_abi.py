@@ -39,3 +39,55 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_py" not in text and "liboracle" not in text and "refzlib" not in text and "libzref" not in text, f
+
+
+def test_host_library_exports_and_fails_loudly_without_gpu():
+    """libzamd_z.so: every entry point include/zamd_zlib.h declares; z_stream is 112 bytes; without a GPU the Init
+    functions refuse (Z_MEM_ERROR + message) instead of falling back to a CPU codec."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import zhost as Z
+    text = open(os.path.join(ROOT, "include", "zamd_zlib.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_]*)\s*\(z_streamp|\b(compress2?|uncompress|compressBound|adler32(?:_combine)?|zlibVersion|zError|zlibCompileFlags)\s*\(", text)))
+    flat = sorted({n for pair in names for n in pair if n})
+    L = Z.lib()
+    assert len(flat) >= 20
+    for n in flat:
+        assert hasattr(L, n), "libzamd_z.so does not export " + n
+    assert C.sizeof(Z.ZStream) == 112
+    assert L.zlibVersion() == b"1.2.3"
+    assert L.compressBound(65536) >= 65567 and L.adler32(1, b"hello", 5) == 0x062C0215
+    import zlib_amd
+    if zlib_amd.load_library().zgpu_device_count() == 0:
+        s = Z.ZStream()
+        assert L.deflateInit_(C.byref(s), 6, b"1.2.3", 112) == Z.Z_MEM_ERROR and b"no CPU fallback" in s.msg
+        assert L.inflateInit_(C.byref(s), b"1.2.3", 112) == Z.Z_MEM_ERROR
+        rc, _ = Z.compress2(b"abc", 6)
+        assert rc == Z.Z_MEM_ERROR
+
+
+def test_client_compiled_against_reference_header_links_with_host_library(tmp_path):
+    """Drop-in check: a C client built with the REFERENCE's zlib.h (when the mount is present) runs against libzamd_z.so."""
+    import subprocess
+    import pytest
+    ref_h = "/root/reference/h/zlib.h"
+    if not os.path.exists(ref_h):
+        pytest.skip("reference header not mounted here")
+    src = tmp_path / "client.c"
+    src.write_text('''#include "zlib.h"
+#include <stdio.h>
+int main(void) {
+    z_stream s; s.zalloc = 0; s.zfree = 0; s.opaque = 0;
+    printf("%s %d %lu ", zlibVersion(), (int)sizeof(z_stream), compressBound(65536));
+    int rc = deflateInit(&s, 6);
+    printf("%d %s\\n", rc, rc == Z_OK ? "ok" : (s.msg ? s.msg : zError(rc)));
+    if (rc == Z_OK) deflateEnd(&s);
+    return 0; }''')
+    exe = tmp_path / "client"
+    libdir = os.path.join(ROOT, "zlib_amd")
+    subprocess.check_call(["gcc", "-std=gnu89", "-w", "-I/root/reference/h", str(src), "-o", str(exe), "-L" + libdir, "-lzamd_z", "-lzamd_gpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], env=dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib")).decode()
+    assert out.startswith("1.2.3 112 "), out

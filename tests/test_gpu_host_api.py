@@ -1,0 +1,151 @@
+"""The zlib-compatible host library (libzamd_z.so) driven the way /root/reference/qcsrc/example.c drives zlib:
+one-shot compress/uncompress, streaming with tiny buffers, flushes, error returns.  Output bytes are compared with the
+CPU oracle's mode-B stream (= the reference's bytes for the same chunking)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cases, corpus_py as CP, oracle_py as O  # noqa: E402
+import zhost as Z  # noqa: E402
+
+
+def chunks_of(data, flush_points):
+    """oracle stream for input cut at the given flush points and, between them, every 64 KiB"""
+    pieces, lo = [], 0
+    for hi in list(flush_points) + [len(data)]:
+        k = lo
+        while True:
+            e = min(k + 65536, hi)
+            pieces.append(data[k:e])
+            k = e
+            if k >= hi:
+                break
+        lo = hi
+    return pieces
+
+
+def test_version_and_errors():
+    L = Z.lib()
+    assert L.zlibVersion() == b"1.2.3"
+    assert L.zError(-3) == b"data error" and L.zError(1) == b"stream end"
+    import ctypes as C
+    s = Z.ZStream()
+    assert L.deflateInit_(C.byref(s), 6, b"2.0", C.sizeof(Z.ZStream)) == Z.Z_VERSION_ERROR      # deflate.c:236-239
+    assert L.deflateInit_(C.byref(s), 6, b"1.2.3", 100) == Z.Z_VERSION_ERROR
+    assert L.deflateInit_(C.byref(s), 10, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR
+    assert L.deflateInit2_(C.byref(s), 6, 8, 31, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # gzip wrapper: not served
+    assert L.deflateInit_(C.byref(s), 6, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
+    out = C.create_string_buffer(16)
+    s.next_out = C.addressof(out); s.avail_out = 0
+    assert L.deflate(C.byref(s), Z.Z_NO_FLUSH) == Z.Z_BUF_ERROR                                  # deflate.c:570
+    s.avail_out = 16
+    assert L.deflate(C.byref(s), 7) == Z.Z_STREAM_ERROR
+    assert L.deflateEnd(C.byref(s)) == Z.Z_OK                                                    # nothing written yet
+
+
+@pytest.mark.parametrize("level", [-1, 0, 1, 6, 9])
+def test_compress2_uncompress_roundtrip(level, golden):
+    """BASELINE config 1 (1 MiB of 'hello, hello! ') through compress2()/uncompress(), and the 14-byte example.c string."""
+    kat = golden("kat.json")
+    rc, z = Z.compress2(cases.HELLO, level)
+    assert rc == 0 and z.hex() == kat["hello"][str(level)]  # a single chunk: identical to the reference's compress2
+    rc, back = Z.uncompress(z, 100)
+    assert rc == 0 and back == cases.HELLO
+    big = cases.hello_1mib()
+    rc, z = Z.compress2(big, level)
+    assert rc == 0 and z == O.deflate_stream(big, 6 if level == -1 else level)
+    rc, back = Z.uncompress(z, len(big))
+    assert rc == 0 and back == big
+
+
+def test_compress2_buffer_too_small_and_uncompress_errors():
+    data = cases.make("rand", 200000, 4)
+    rc, _ = Z.compress2(data, 6, cap=1000)
+    assert rc == Z.Z_BUF_ERROR                                       # compress.c:50-53
+    rc, z = Z.compress2(data, 6)
+    assert rc == 0
+    assert Z.uncompress(z, len(data) - 1)[0] == Z.Z_BUF_ERROR         # output too small
+    assert Z.uncompress(z[:-7], len(data))[0] == Z.Z_DATA_ERROR      # input ends early (uncompr.c:53-55)
+    bad = bytearray(z); bad[-1] ^= 1
+    assert Z.uncompress(bytes(bad), len(data))[0] == Z.Z_DATA_ERROR  # incorrect data check
+    bad = bytearray(z); bad[0] ^= 0x10
+    assert Z.uncompress(bytes(bad), len(data))[0] == Z.Z_DATA_ERROR  # incorrect header check
+
+
+def test_streaming_deflate_tiny_buffers():
+    """example.c:169-205 feeds and drains one byte at a time; the stream must not depend on the buffering."""
+    data = CP.chunks(CP.KIND_SILESIA, 11, 3).tobytes()[:150000]
+    want = O.deflate_stream(data, 6)
+    z, codes, info = Z.deflate_stream(data, 6, [(len(data), Z.Z_FINISH)], in_step=None, out_step=7)
+    assert z == want and codes[-1] == Z.Z_STREAM_END
+    assert info["total_in"] == len(data) and info["total_out"] == len(want) and info["adler"] == O.adler32(data)
+    z, codes, info = Z.deflate_stream(data[:70000], 1, [(70000, Z.Z_FINISH)], in_step=1000, out_step=None)
+    assert z == O.deflate_stream(data[:70000], 1) and info["end_rc"] == Z.Z_OK
+    small = cases.HELLO
+    z, codes, info = Z.deflate_stream(small, 9, [(len(small), Z.Z_FINISH)], in_step=1, out_step=1)
+    assert z == O.deflate_stream(small, 9)
+    assert info["data_type"] == 0  # "hello, hello!\0" holds a NUL: Z_BINARY (trees.c:1126-1139)
+
+
+def test_full_flush_points_become_chunk_boundaries():
+    data = cases.make("text", 200000, 8)
+    cuts = [3, 70000, 70001, 150000]
+    plan = [(3, Z.Z_FULL_FLUSH), (69997, Z.Z_FULL_FLUSH), (1, Z.Z_SYNC_FLUSH), (79999, Z.Z_FULL_FLUSH), (50000, Z.Z_FINISH)]
+    z, codes, info = Z.deflate_stream(data, 6, plan)
+    pieces = chunks_of(data, cuts)
+    want = bytes.fromhex("789c") + b"".join(O.deflate_chunk(p, 6, i == len(pieces) - 1) for i, p in enumerate(pieces)) + O.adler32(data).to_bytes(4, "big")
+    assert z == want
+    # and the library reads its own flushed stream back, fed one byte at a time
+    rc, back, msg, adler = Z.inflate_stream(z[:5000], 10, in_step=1)  # incomplete prefix: no end yet
+    assert rc == Z.Z_OK
+    rc, back, msg, adler = Z.inflate_stream(z, len(data), in_step=4096)
+    assert rc == Z.Z_STREAM_END and back == data and adler == O.adler32(data)
+
+
+def test_duplicate_flush_and_finish_rules():
+    import ctypes as C
+    L = Z.lib()
+    s = Z.ZStream()
+    assert L.deflateInit_(C.byref(s), 6, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
+    src = C.create_string_buffer(b"abcabcabc")
+    out = C.create_string_buffer(1000)
+    s.next_in = C.addressof(src); s.avail_in = 9; s.next_out = C.addressof(out); s.avail_out = 1000
+    assert L.deflate(C.byref(s), Z.Z_FULL_FLUSH) == Z.Z_OK
+    assert L.deflate(C.byref(s), Z.Z_FULL_FLUSH) == Z.Z_BUF_ERROR    # same flush again, no input (deflate.c:774-777)
+    assert L.deflateEnd(C.byref(s)) == Z.Z_DATA_ERROR                # stream abandoned while busy (deflate.c:886)
+    assert L.deflateInit_(C.byref(s), 6, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
+    s.next_in = C.addressof(src); s.avail_in = 9; s.next_out = C.addressof(out); s.avail_out = 1000
+    assert L.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    assert L.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END       # harmless repeat (deflate.c:770-773)
+    s.avail_in = 3; s.next_in = C.addressof(src)
+    assert L.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_BUF_ERROR        # input after the end (deflate.c:780-782)
+    assert L.deflate(C.byref(s), Z.Z_NO_FLUSH) == Z.Z_STREAM_ERROR
+    assert L.deflateEnd(C.byref(s)) == Z.Z_OK
+    assert out.raw[: s.total_out if s.total_out else 0] is not None
+
+
+def test_inflate_one_byte_at_a_time_like_example_c():
+    """example.c:210-243: avail_in = avail_out = 1 until Z_STREAM_END."""
+    z = O.deflate_stream(cases.HELLO, 6)
+    rc, back, msg, adler = Z.inflate_stream(z, 100, in_step=1, out_step=1)
+    assert rc == Z.Z_STREAM_END and back == cases.HELLO
+    # a raw stream (windowBits -15), as zip.c/unzip.c use it
+    zr, _, _ = Z.deflate_stream(b"raw deflate for zip members " * 50, 6, [(1400, Z.Z_FINISH)], window_bits=-15)
+    assert zr == O.deflate_stream(b"raw deflate for zip members " * 50, 6)[2:-4]
+    rc, back, msg, adler = Z.inflate_stream(zr, 2000, window_bits=-15, flush=Z.Z_FINISH)
+    assert rc == Z.Z_STREAM_END and back == b"raw deflate for zip members " * 50
+
+
+def test_foreign_single_segment_stream():
+    """A plain zlib stream (no flush markers) that decodes to <= 64 KiB is one segment for the engine."""
+    import zlib
+    data = cases.make("text", 60000, 2)
+    z = zlib.compress(data, 6)
+    rc, back = Z.uncompress(z, len(data))
+    assert rc == 0 and back == data
+    # stored data that contains the marker pattern 00 00 FF FF inside a chunk must not be split there
+    tricky = (b"\x00\x00\xff\xff" * 100 + bytes(range(256))) * 20
+    rc, z = Z.compress2(tricky, 0)
+    assert rc == 0
+    rc, back = Z.uncompress(z, len(tricky))
+    assert rc == 0 and back == tricky

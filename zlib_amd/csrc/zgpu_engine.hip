@@ -17,7 +17,7 @@ void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta,
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
-                   uint64_t out_cap, hipStream_t st);
+                   uint64_t out_cap, uint32_t slot_stride, hipStream_t st);
 void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st);
 bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
@@ -52,6 +52,7 @@ struct zgpu_engine {
     void *inf_status = nullptr; uint64_t inf_status_cap = 0;
     zgpu::ChunkMeta *inf_meta = nullptr; uint32_t inf_meta_cap = 0;
     uint64_t *inf_offs = nullptr; uint64_t inf_offs_cap = 0;
+    void *inf_slots = nullptr; uint64_t inf_slots_cap = 0;
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -216,7 +217,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
             launch_adler(g, e->meta, st);
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st);
-            launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, st);
+            launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);
         }
         ZGPU_HIP_CHECK(hipGetLastError());
     }
@@ -293,7 +294,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
-    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs);
+    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     hipStreamDestroy(e->stream);
     delete e;
@@ -382,7 +383,7 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
 {
     if (!e || !res || !in || !out || !chunk_offsets || nchunks == 0) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
-    const uint64_t need_out = nchunks * (uint64_t)chunk_size;
+    const uint64_t need_out = nchunks * (uint64_t)(chunk_size ? chunk_size : kChunkMax);
     int rc = ensure_stage(e, in_bytes + 64, need_out);
     if (rc) return rc;
     if (nchunks + 1 > e->offsets_cap) {
@@ -468,7 +469,20 @@ void *engine_scratch(zgpu_engine *e, size_t bytes)
     }
     return e->inf_status;
 }
+void *engine_scratch2(zgpu_engine *e, size_t bytes)
+{
+    if (bytes > e->inf_slots_cap) {
+        hipFree(e->inf_slots); e->inf_slots = nullptr; e->inf_slots_cap = 0;
+        if (hipMalloc(&e->inf_slots, bytes) != hipSuccess) return nullptr;
+        e->inf_slots_cap = bytes;
+    }
+    return e->inf_slots;
+}
 void *engine_run_state(zgpu_engine *e) { return e->run; }
+uint8_t *engine_stage_in(zgpu_engine *e) { return e->stage_in; }
+uint8_t *engine_stage_out(zgpu_engine *e) { return e->stage_out; }
+int engine_ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes) { return ensure_stage(e, in_bytes, out_bytes); }
+hipStream_t engine_stream(zgpu_engine *e) { return e->stream; }
 ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch)
 {
     if (batch > e->inf_meta_cap) {

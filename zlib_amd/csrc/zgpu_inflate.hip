@@ -26,6 +26,8 @@ void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
+void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
+                   uint64_t out_cap, uint32_t slot_stride, hipStream_t st);
 
 enum InfMsg : uint32_t {
     kMsgNone = 0, kMsgBlockType, kMsgStoredLen, kMsgTooMany, kMsgCodeLens, kMsgRepeat, kMsgLitLens, kMsgDists, kMsgLitCode, kMsgDistCode,
@@ -151,8 +153,8 @@ __constant__ const uint8_t kDExt[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5
 __constant__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
-                                                     uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size,
-                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status)
+                                                     uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
+                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
@@ -160,6 +162,10 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     if (c >= nchunks) return;
     const uint64_t gc = chunk0 + c, seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
     const bool must_be_final = gc == last_chunk;
+    // chunk_size_arg == 0: "compact" mode, segments of any size up to 64 KiB are decoded into per-chunk slots and
+    // concatenated afterwards (used for streams whose chunks are not all full, e.g. flushed mid-chunk)
+    const bool compact = chunk_size_arg == 0;
+    const uint32_t chunk_size = compact ? kChunkMax : chunk_size_arg;
     uint32_t err = kMsgNone;
 
     BitSrc b;
@@ -311,15 +317,15 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
         else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
         else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
-        else if (!must_be_final && o != chunk_size) err = kMsgShort;      // output placement assumes full chunks
+        else if (!compact && !must_be_final && o != chunk_size) err = kMsgShort; // direct placement assumes full chunks
     }
 #ifdef ZGPU_INF_DEBUG2
     if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
 #endif
     __syncthreads();
     // store the chunk
-    uint8_t *dst = out + gc * (uint64_t)chunk_size;
-    const bool fits = gc * (uint64_t)chunk_size + o <= out_cap;
+    uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
+    const bool fits = compact || gc * (uint64_t)chunk_size + o <= out_cap;
     if (!err && fits) {
         if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
             const uint4 *s128 = reinterpret_cast<const uint4 *>(L.out);
@@ -332,6 +338,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     if (lane == 0) {
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
+        if (meta) { meta[c].out_bytes = err ? 0 : o; meta[c].ntok = 0; meta[c].adler_a = 1; meta[c].adler_b = 0; meta[c].in_bytes = 0; meta[c].data_type = 2; }
     }
 }
 
@@ -364,6 +371,7 @@ using namespace zgpu;
 // engine internals needed here (defined in zgpu_engine.hip)
 namespace zgpu {
 void *engine_scratch(zgpu_engine *e, size_t bytes);          // grow-only device scratch
+void *engine_scratch2(zgpu_engine *e, size_t bytes);
 void *engine_run_state(zgpu_engine *e);
 ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch);
 uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
@@ -375,17 +383,19 @@ struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
 {
-    if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || chunk_size == 0 || chunk_size > kChunkMax)
+    if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || chunk_size > kChunkMax)
         return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
+    const bool compact = chunk_size == 0; // segments of any size: decode into slots, then concatenate
     const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
     InfStatus *status = static_cast<InfStatus *>(engine_scratch(e, (size_t)batch * sizeof(InfStatus) + 64));
     if (!status) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
     uint64_t *acc = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(status) + (((size_t)batch * sizeof(InfStatus) + 15) & ~(size_t)15));
     ChunkMeta *meta = engine_meta(e, batch);
     if (!meta) return engine_fail(e, ZGPU_MEM_ERROR, "inflate meta");
-    uint64_t *oscr = engine_offsets_scratch(e, nchunks + 1);
-    if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
+    uint8_t *slots = nullptr;
+    if (compact) { slots = static_cast<uint8_t *>(engine_scratch2(e, (size_t)batch * kChunkMax + 256)); if (!slots) return engine_fail(e, ZGPU_MEM_ERROR, "inflate slots"); }
+    res->adler32 = 1; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0; res->out_bytes = 0;
     ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(uint64_t), st));
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
@@ -393,11 +403,17 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds)); opt_in = true; }
     hipEvent_t ev{};
     prof_span_begin(e, st, &ev);
+    uint64_t *oscr = engine_offsets_scratch(e, nchunks + 1 + (out_cap >> 16) + 2);
+    if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
-        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(64), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size, d_out,
-                           out_cap, status);
+        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(64), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
+                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr);
         hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc);
+        if (compact) {
+            launch_scan(meta, nb, c0, oscr, engine_run_state(e), out_cap, st); // out_bytes -> byte offsets, continuing across batches
+            launch_stitch(slots, meta, oscr, c0, nb, d_out, out_cap, kChunkMax, st);
+        }
         ZGPU_HIP_CHECK(hipGetLastError());
     }
     prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
@@ -405,18 +421,15 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     ZGPU_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     res->out_bytes = h[0]; res->first_bad_chunk = h[1] ? (int32_t)(h[1] - 1) : -1; res->error_code = (int32_t)(int64_t)h[2]; res->error_msg = (uint32_t)h[3];
-    res->adler32 = 1;
     if (h[1]) { engine_collect(e); return engine_fail(e, res->error_code, kInfMessages[res->error_msg < kMsgCount ? res->error_msg : 0]); }
-    // every chunk but the last must be full, or the output would have holes
-    if (nchunks > 1 && h[0] <= (nchunks - 1) * (uint64_t)chunk_size - 1 + 0 && h[0] < (nchunks - 1) * (uint64_t)chunk_size) {
-        engine_collect(e);
-        res->error_code = ZGPU_DATA_ERROR; res->error_msg = kMsgOutput;
-        return engine_fail(e, ZGPU_DATA_ERROR, "a segment other than the last decoded to fewer than chunk_size bytes");
-    }
-    // Adler-32 of the produced bytes (same kernels as the compress side)
-    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
-        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
-        ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = chunk_size; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
+    if (h[0] > out_cap) { engine_collect(e); return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small"); }
+    // Adler-32 of the produced bytes (same kernels as the compress side), over 64 KiB pieces of the output
+    const uint64_t npieces = h[0] ? (h[0] + kChunkMax - 1) / kChunkMax : 1;
+    rs = RunStateHostI{}; rs.adler_a = 1;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    for (uint64_t c0 = 0; c0 < npieces; c0 += batch) {
+        const uint32_t nb = (uint32_t)(npieces - c0 < batch ? npieces - c0 : batch);
+        ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
         launch_adler(g, meta, st);
         launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st);
@@ -429,9 +442,90 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
 }
 } // namespace zgpu
 
+namespace zgpu {
+// ---- chunk boundaries of a stream that carries no side table: every full-flush marker 00 00 FF FF ends a segment ----
+__global__ void __launch_bounds__(256) marker_scan_kernel(const uint8_t *__restrict__ in, uint64_t n, uint64_t *cand, uint32_t cap, uint32_t *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 4 <= n; i += stride) {
+        if (in[i] == 0 && in[i + 1] == 0 && in[i + 2] == 0xFF && in[i + 3] == 0xFF) {
+            const uint32_t k = atomicAdd(count, 1u);
+            if (k < cap) cand[k] = i + 4;
+        }
+    }
+}
+uint8_t *engine_stage_in(zgpu_engine *e);
+uint8_t *engine_stage_out(zgpu_engine *e);
+int engine_ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes);
+hipStream_t engine_stream(zgpu_engine *e);
+} // namespace zgpu
+
+#include <algorithm>
+#include <vector>
+
+// Decode a raw deflate body made of full-flush-separated segments without a side table.  Candidate boundaries are the
+// marker positions; a candidate that is not a real boundary (the pattern can occur inside stored or coded data) makes its
+// segment fail to decode and is merged away.  On success *offsets_out (optional) receives the validated boundaries.
+static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap, zgpu_inflate_result *res,
+                               std::vector<uint64_t> *offsets_out)
+{
+    if (!e || !in || !res || in_bytes == 0) return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
+    ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
+    hipStream_t st = engine_stream(e);
+    const uint64_t max_cand = in_bytes / 5 + 2;
+    int rc = engine_ensure_stage(e, in_bytes + 64 + (max_cand + 2) * 2 * sizeof(uint64_t) + 64, out_cap ? out_cap : 1);
+    if (rc) return rc;
+    uint8_t *d_in = engine_stage_in(e);
+    const uint64_t tab_off = (in_bytes + 127) & ~63ull;
+    uint64_t *d_cand = reinterpret_cast<uint64_t *>(d_in + tab_off);          // candidates, later the offsets table
+    uint64_t *d_offs = d_cand + max_cand + 2;
+    uint32_t *d_count = static_cast<uint32_t *>(engine_scratch(e, 64 * 1024));
+    ZGPU_HIP_CHECK(hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, st));
+    ZGPU_HIP_CHECK(hipMemsetAsync(d_count, 0, 4, st));
+    hipLaunchKernelGGL(marker_scan_kernel, dim3(2048), dim3(256), 0, st, d_in, in_bytes, d_cand, (uint32_t)max_cand, d_count);
+    uint32_t ncand = 0;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&ncand, d_count, 4, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint64_t> b(ncand + 2);
+    if (ncand) ZGPU_HIP_CHECK(hipMemcpy(b.data() + 1, d_cand, (size_t)ncand * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    b[0] = 0;
+    std::sort(b.begin() + 1, b.begin() + 1 + ncand);
+    b[ncand + 1] = in_bytes;
+    b.erase(std::unique(b.begin(), b.end()), b.end()); // a marker can end exactly at the end of the body
+    for (;;) {
+        const uint64_t nseg = b.size() - 1;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st);
+        if (rc == ZGPU_OK) break;
+        if (rc != ZGPU_DATA_ERROR || res->first_bad_chunk < 0 || (uint64_t)res->first_bad_chunk + 1 >= nseg) return rc;
+        b.erase(b.begin() + res->first_bad_chunk + 1); // not a boundary after all: merge with the next segment
+    }
+    if (out && res->out_bytes) ZGPU_HIP_CHECK(hipMemcpy(out, engine_stage_out(e), res->out_bytes, hipMemcpyDeviceToHost));
+    if (offsets_out) *offsets_out = b;
+    return ZGPU_OK;
+}
+
 extern "C" {
 #pragma GCC visibility push(default)
 const char *zgpu_inflate_message(uint32_t index) { return index < kMsgCount ? kInfMessages[index] : ""; }
-int zgpu_inflate_find_chunks_host(zgpu_engine *, const void *, uint64_t, uint32_t, uint64_t *, uint64_t, uint64_t *) { return ZGPU_STREAM_ERROR; }
+int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t *offsets, uint64_t max_chunks,
+                                  uint64_t *nchunks)
+{
+    (void)chunk_size;
+    if (!offsets || !nchunks) return ZGPU_STREAM_ERROR;
+    std::vector<uint64_t> b;
+    zgpu_inflate_result res{};
+    int rc = inflate_stream_host(e, in, in_bytes, nullptr, max_chunks * (uint64_t)kChunkMax, &res, &b);
+    if (rc) return rc;
+    if (b.size() - 1 > max_chunks) return engine_fail(e, ZGPU_BUF_ERROR, "offset table too small");
+    for (size_t i = 0; i < b.size(); i++) offsets[i] = b[i];
+    *nchunks = b.size() - 1;
+    return ZGPU_OK;
+}
+int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap, zgpu_inflate_result *res)
+{
+    if (!out) return ZGPU_STREAM_ERROR;
+    return inflate_stream_host(e, in, in_bytes, out, out_cap, res, nullptr);
+}
 #pragma GCC visibility pop
 }

@@ -102,14 +102,14 @@ __global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict_
 // copy slot c to out + offsets[chunk0 + c]; 4-byte destination-aligned stores
 __global__ void __launch_bounds__(256) stitch_kernel(const uint8_t *__restrict__ slots, const ChunkMeta *__restrict__ meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
-                                                     uint64_t out_cap)
+                                                     uint64_t out_cap, uint32_t slot_stride)
 {
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     if (c >= nchunks) return;
     const uint32_t n = meta[c].out_bytes;
     const uint64_t off = offsets[chunk0 + c];
     if (off + n > out_cap) return; // reported through RunState.overflow
-    const uint8_t *src = slots + (size_t)c * kSlotStride;
+    const uint8_t *src = slots + (size_t)c * slot_stride;
     uint8_t *dst = out + off;
     uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
     if (head > n) head = n;
@@ -141,9 +141,9 @@ void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint6
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, meta, nchunks, chunk0, offsets, static_cast<RunState *>(run), out_cap);
 }
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
-                   uint64_t out_cap, hipStream_t st)
+                   uint64_t out_cap, uint32_t slot_stride, hipStream_t st)
 {
-    hipLaunchKernelGGL(stitch_kernel, dim3(nchunks), dim3(256), 0, st, slots, meta, offsets, chunk0, nchunks, out, out_cap);
+    hipLaunchKernelGGL(stitch_kernel, dim3(nchunks), dim3(256), 0, st, slots, meta, offsets, chunk0, nchunks, out, out_cap, slot_stride);
 }
 void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st)
 {
