@@ -311,6 +311,8 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             o += len;
         }
     }
+    // an error found in bits that lie past the end of the segment is the zero padding talking: the segment is truncated
+    if (err && err != kMsgOutput && consumed_bits(b) > b.seg_bits) err = kMsgTruncated;
     if (!err) {
         const uint32_t used = consumed_bits(b);
         if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
