@@ -80,7 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     import zlib_amd
-    from zlib_amd import gpu
+    from zlib_amd import gpu, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,30 +109,20 @@ def main():
     state = {}
 
     def deflate_step():
-        res = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
+        if world == 1:
+            state["res"] = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
+                                              lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
+            return
+        # N > 1: every rank emits the raw body of its chunk range (BFINAL only on the last rank's last chunk); rank 0 gathers
+        # the bodies over RCCL and frames them into one RFC 1950 stream (zlib_amd/shard.py)
+        res = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL if rank == world - 1 else 0,
                                  lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
         state["res"] = res
-        if world > 1:
-            # gather-v of the per-GPU streams to rank 0: sizes first, then point-to-point sends (one xGMI link per peer)
-            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([res.out_bytes], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-            sz = sizes.tolist()
-            nonlocal gather_buf
-            if rank == 0:
-                total = sum(sz)
-                if gather_buf is None or gather_buf.numel() < total:
-                    gather_buf = torch.empty(int(total * 1.05) + 4096, dtype=torch.uint8, device=dev)
-                gather_buf[: sz[0]].copy_(dst[: sz[0]])
-                reqs, o = [], sz[0]
-                for r in range(1, world):
-                    reqs.append(dist.irecv(gather_buf[o: o + sz[r]], src=r))
-                    o += sz[r]
-                for q in reqs:
-                    q.wait()
-                state["gathered"] = total
-            else:
-                dist.send(dst[: res.out_bytes], dst=0)
+        nonlocal gather_buf
+        if rank == 0 and gather_buf is None:
+            gather_buf = torch.empty(int(cap * world * 0.6) + 4096, dtype=torch.uint8, device=dev)
+        stream_t, total = shard.gather_stream(dst[: res.out_bytes], res.adler32, nbytes, a.level, out=gather_buf)
+        state["gathered"] = total
 
     def inflate_step():
         r = eng.inflate_device(state["z_ptr"], state["z_len"], offs.data_ptr(), nchunks, src2.data_ptr(), nbytes, stream=stream)

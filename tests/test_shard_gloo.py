@@ -1,0 +1,70 @@
+"""The multi-GPU stream assembly (zlib_amd/shard.py) on CPU: world_size 2 and 3 over gloo, per-rank compression done by
+the CPU oracle.  The gathered stream must be byte-identical to the single-process mode-B stream of the whole input."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cases, oracle_py as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, data, level, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zlib_amd import shard
+    nchunks = max(1, (len(data) + 65535) // 65536)
+    lo, hi = shard.chunk_range(nchunks, rank, world)
+    mine = data[lo * 65536: hi * 65536]
+    segs = [O.deflate_chunk(mine[k * 65536:(k + 1) * 65536], level, (lo + k == nchunks - 1)) for k in range(hi - lo)]
+    body = torch.frombuffer(bytearray(b"".join(segs)), dtype=torch.uint8) if segs else torch.empty(0, dtype=torch.uint8)
+    stream, total = shard.gather_stream(body, O.adler32(mine), len(mine), level)
+    if rank == 0:
+        q.put(bytes(stream.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbytes", [(2, 65536 * 5 + 1234), (3, 65536 * 7), (2, 65536 + 1)])
+def test_gathered_stream_equals_single_process_stream(world, nbytes):
+    data = cases.make("mix", nbytes, 17)
+    level = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, data, level, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == O.deflate_stream(data, level)
+    rc, out, used, msg = O.inflate_zlib(got, len(data))
+    assert rc == 1 and out == data
+
+
+def test_chunk_ranges_cover_everything():
+    from zlib_amd import shard
+    for n in (1, 2, 7, 8, 65536, 1048576):
+        for w in (1, 2, 3, 4, 8):
+            r = [shard.chunk_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_adler_join_matches_oracle():
+    from zlib_amd import shard
+    a, b = cases.make("rand", 70001, 1), cases.make("text", 12345, 2)
+    assert shard.adler_join(O.adler32(a), O.adler32(b), len(b)) == O.adler32(a + b)
+    assert shard.adler_join(1, O.adler32(b), len(b)) == O.adler32(b)
