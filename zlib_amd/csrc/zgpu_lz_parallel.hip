@@ -33,6 +33,15 @@ constexpr uint32_t kNoLink = 0; // links are stored as q+1 (q = position of the 
 constexpr uint32_t kTile = 8192, kRing = 40960; // ring >= MAX_DIST + tile: 40960 links = 80 KiB
 constexpr uint32_t kMatchThreads = 1024;
 constexpr int kSlots = 1; // positions a lane walks concurrently (1 or 2)
+#ifndef ZGPU_REFILL_MIN
+#define ZGPU_REFILL_MIN 16
+#endif
+#ifndef ZGPU_CMP_MIN
+#define ZGPU_CMP_MIN 16
+#endif
+#ifndef ZGPU_WALK_UNROLL
+#define ZGPU_WALK_UNROLL 8
+#endif
 
 struct ParWorkspace { uint16_t *links; uint2 *recs; };
 
@@ -40,14 +49,18 @@ size_t lz_parallel_workspace_bytes(uint32_t batch) { return (size_t)batch * kChu
 bool lz_parallel_available() { return true; }
 
 // ------------------------------------------------------------------------------------------------- K1
-// One wave per chunk.  The input is consumed in 256-byte blocks: each lane fetches one dword of the *next* block
-// while the current one is processed (global latency hidden), blocks are staged in a small LDS buffer so that the
-// three bytes of a position are aligned byte reads.  head[] (LDS, 64 KiB) holds p+1 of the latest position of each
-// hash, 0 = empty.
+// One wave per chunk.  head[] (LDS, 64 KiB) holds p+1 of the latest position of each hash, 0 = empty, and is updated in
+// position order, 64 positions per step.  Global memory is touched once per 1024 positions only: the next 1 KiB of input
+// is fetched into registers while the current one is processed, and the links of the previous 1 KiB are written out from
+// an LDS staging buffer -- so the single vmcnt wait per kilobyte finds its loads and stores long finished (per-step
+// stores made every step wait for the previous step's stores: loads and stores share one counter on gfx9).
+constexpr uint32_t kSuper = 1024; // positions per superblock
+
 __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__restrict__ links)
 {
     __shared__ uint16_t head[kHashSize];
-    __shared__ uint32_t stage[2][66]; // two 256-byte blocks (+8 bytes of the following block)
+    __shared__ __attribute__((aligned(16))) uint32_t in_stage[kSuper / 4 + 4]; // 1 KiB of input + 8 bytes of the next KiB
+    __shared__ __attribute__((aligned(16))) uint16_t link_stage[kSuper];
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
@@ -56,28 +69,36 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
     for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0; // positions 0 .. n-3 carry a hash
     volatile uint16_t *vhead = head;          // the claim/read-back below must really go through LDS
-    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3) == 0;
-    auto fetch = [&](uint32_t blk) -> uint32_t { // dword `lane` of block blk, zero padded past n
-        const uint32_t a = blk * 256 + lane * 4;
-        if (a + 4 <= n && aligned) return *reinterpret_cast<const uint32_t *>(src + a);
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < 4; k++) if (a + k < n) v |= (uint32_t)src[a + k] << (8 * k);
-        return v;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    auto fetch = [&](uint32_t sb) -> uint4 { // 16 bytes: bytes [sb*1024 + lane*16, +16) of the chunk, zero padded past n
+        const uint32_t a = sb * kSuper + lane * 16;
+        if (a + 16 <= n && aligned) return *reinterpret_cast<const uint4 *>(src + a);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < 16; k++) if (a + k < n) w[k >> 2] |= (uint32_t)src[a + k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
     };
-    const uint32_t nblk = (npos + 255) / 256;
-    uint32_t cur = nblk ? fetch(0) : 0, nxt = nblk > 1 || n > 256 ? fetch(1) : 0;
+    const uint32_t nsuper = (n + kSuper - 1) / kSuper;
+    uint4 cur = fetch(0), nxt = fetch(1);
     __syncthreads();
-    for (uint32_t b = 0; b < nblk; b++) {
-        uint32_t *st = stage[b & 1];
-        st[lane] = cur;
-        if (lane < 2) st[64 + lane] = __shfl(nxt, lane); // first 8 bytes of the next block
-        const uint32_t nn = (b + 2) * 256 < n + 256 ? fetch(b + 2) : 0; // prefetch two blocks ahead
-        const uint8_t *s8 = reinterpret_cast<const uint8_t *>(st);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const uint8_t *s8 = reinterpret_cast<const uint8_t *>(in_stage);
+    for (uint32_t sb = 0; sb < nsuper; sb++) {
+        // input of this superblock -> LDS (the registers were loaded one superblock ago)
+        reinterpret_cast<uint4 *>(in_stage)[lane] = cur;
+        if (lane == 0) { in_stage[kSuper / 4] = nxt.x; in_stage[kSuper / 4 + 1] = nxt.y; }
+        // links of the previous superblock -> global, 32 bytes per lane
+        if (sb > 0) {
+            const uint32_t p0 = (sb - 1) * kSuper + lane * 16;
+            const uint4 *ls = reinterpret_cast<const uint4 *>(link_stage);
+            if (p0 + 16 <= n) { uint4 *dst = reinterpret_cast<uint4 *>(lk + p0); dst[0] = ls[lane * 2]; dst[1] = ls[lane * 2 + 1]; }
+            else for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) lk[p0 + k] = link_stage[lane * 16 + k];
+        }
+        cur = nxt;
+        nxt = fetch(sb + 2);
+        __syncthreads();
+        const uint32_t base_p = sb * kSuper;
 #pragma unroll 1
-        for (uint32_t sb = 0; sb < 4; sb++) {
-            const uint32_t o = sb * 64 + lane, p = b * 256 + o, p0 = b * 256 + sb * 64;
-            if (p0 >= npos) break;
+        for (uint32_t st = 0; st < kSuper / 64; st++) {
+            const uint32_t o = st * 64 + lane, p = base_p + o, p0 = base_p + st * 64;
             const bool live = p < npos;
             uint32_t h = 0, old = kNoLink;
             if (live) { h = hash3(s8[o], s8[o + 1], s8[o + 2]); old = vhead[h]; }
@@ -90,7 +111,7 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
             unsigned long long clash = __ballot(live && seen != p + 1);
             while (clash) {
                 const int f = __ffsll((long long)clash) - 1;
-                const uint32_t h0 = __shfl(h, f);
+                const uint32_t h0 = __builtin_amdgcn_readlane(h, f); // f is wave-uniform: v_readlane, no LDS round trip
                 const unsigned long long grp = __ballot(live && h == h0);
                 if (live && h == h0) {
                     const unsigned long long below = grp & ((1ull << lane) - 1);
@@ -100,11 +121,14 @@ __global__ void __launch_bounds__(64) chain_kernel(ChunkGeom g, uint16_t *__rest
                 clash &= ~grp;
             }
             if (live && last) vhead[h] = (uint16_t)(p + 1);
-            if (live) lk[p] = (uint16_t)link;
+            link_stage[o] = (uint16_t)(live ? link : kNoLink);
         }
-        cur = nxt; nxt = nn;
+        __syncthreads();
     }
-    for (uint32_t p = npos + lane; p < n; p += 64) lk[p] = (uint16_t)kNoLink;
+    if (nsuper) { // links of the last superblock
+        const uint32_t p0 = (nsuper - 1) * kSuper + lane * 16;
+        for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) lk[p0 + k] = link_stage[lane * 16 + k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- K2
@@ -232,7 +256,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
             const uint32_t nfree = 64 * kSlots - nw - nc;
 
             // ---- REFILL: store finished records, hand out new positions ----
-            if (nfree >= 16 * kSlots || nw + nc == 0) {
+            if (nfree >= ZGPU_REFILL_MIN * kSlots || nw + nc == 0) {
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) {
                     WalkLane &z = s[j];
@@ -291,7 +315,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
             }
 
             // ---- COMPARE: when many slots wait for a full comparison, or few can walk ----
-            if (nc >= 16 * kSlots || (nc > 0 && nw < 16 * kSlots)) {
+            if (nc >= ZGPU_CMP_MIN * kSlots || (nc > 0 && nw < 16 * kSlots)) {
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) {
                     WalkLane &z = s[j];
@@ -318,7 +342,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(ChunkGeom g, Level
 
             // ---- WALK: a few candidates per slot; the quick-reject bytes and the next link are fetched together ----
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < ZGPU_WALK_UNROLL; k++) {
                 bool w[kSlots], any = false;
 #pragma unroll
                 for (int j = 0; j < kSlots; j++) { w[j] = s[j].mode == kWalk; any = any || w[j]; }

@@ -32,7 +32,8 @@ class InflateResult(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libzamd_gpu.so")
+    # ZAMD_GPU_LIB: load another build of the engine (A/B measurements of kernel variants)
+    return os.environ.get("ZAMD_GPU_LIB") or os.path.join(_HERE, "libzamd_gpu.so")
 
 
 def load_library():
