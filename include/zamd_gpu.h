@@ -47,7 +47,8 @@ extern "C" {
 /* LZ77 match-finder implementation selector (debug / A-B measurements) */
 #define ZGPU_LZ_AUTO 0
 #define ZGPU_LZ_SERIAL 1   /* one lane per chunk, tables in HBM: any level 1..9 */
-#define ZGPU_LZ_PARALLEL 2 /* static-chain search over all positions + scan parse: levels 4..9 */
+#define ZGPU_LZ_PARALLEL 2 /* static-chain search over all positions (link ring in LDS) + scan parse: levels 4..9 */
+#define ZGPU_LZ_SORTED 3   /* the same search over counting-sorted hash buckets: levels 4..9 */
 
 typedef struct zgpu_engine zgpu_engine;
 

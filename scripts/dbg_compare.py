@@ -26,10 +26,11 @@ def cmp(data, lvl, impl=gpu.LZ_AUTO, cs=65536, label=""):
 
 
 if __name__ == "__main__":
+    IMPL = int(os.environ.get("DBG_IMPL", "0"))
     big = cases.hello_1mib()
-    for lvl in (1, 6, 9):
-        cmp(big, lvl, label="hello1m")
-    for lvl in (1, 6):
-        cmp(big[:65536 * 2], lvl, label="hello128k")
-        cmp(big[:65536 + 10], lvl, label="hello64k+10")
-        cmp(CP.chunks(0, 0, 4).tobytes(), lvl, label="corpus4")
+    for lvl in (6, 9):
+        cmp(big, lvl, impl=IMPL, label="hello1m")
+    for lvl in (4, 6):
+        cmp(big[:65536 * 2], lvl, impl=IMPL, label="hello128k")
+        cmp(big[:65536 + 10], lvl, impl=IMPL, label="hello64k+10")
+        cmp(CP.chunks(0, 0, 4).tobytes(), lvl, impl=IMPL if lvl >= 4 else 0, label="corpus4")

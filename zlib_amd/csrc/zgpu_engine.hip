@@ -22,6 +22,8 @@ void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t 
 bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
+size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
 
@@ -133,7 +135,8 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
     }
     if (!serial && batch > e->par_cap) {
         hipFree(e->par_ws); e->par_ws = nullptr; e->par_cap = 0;
-        ZGPU_HIP_CHECK(hipMalloc(&e->par_ws, lz_parallel_workspace_bytes(batch)));
+        const size_t wa = lz_parallel_workspace_bytes(batch), wb = lz_sorted_workspace_bytes(batch);
+        ZGPU_HIP_CHECK(hipMalloc(&e->par_ws, wa > wb ? wa : wb));
         e->par_cap = batch;
     }
     if (nchunks_total + 1 > e->offsets_cap) {
@@ -165,8 +168,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const LevelCfg cfg = level_cfg(p->level);
     int impl = p->lz_impl;
     if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_PARALLEL : ZGPU_LZ_SERIAL;
-    if (impl == ZGPU_LZ_PARALLEL && (!cfg.slow || !lz_parallel_available()))
+    if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
+    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     const bool serial = impl == ZGPU_LZ_SERIAL;
     if (d_seg && ((p->flags & ZGPU_F_ZLIB_WRAP) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
@@ -175,7 +179,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     uint32_t batch_max = env_u32("ZGPU_BATCH_CHUNKS", 65536);
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_parallel_workspace_bytes(1));
+        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
@@ -206,7 +210,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
+            if (impl == ZGPU_LZ_SORTED) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
+            else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);

@@ -440,6 +440,11 @@ __global__ void __launch_bounds__(64) parse_kernel(ChunkGeom g, LevelCfg cfg, co
     meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
 }
 
+void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    hipLaunchKernelGGL(parse_kernel, dim3((g.nchunks + 63) / 64), dim3(64), 0, st, g, cfg, recs, tokens, meta);
+}
+
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)
 {
     uint16_t *links = static_cast<uint16_t *>(workspace);

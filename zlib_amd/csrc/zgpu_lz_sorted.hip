@@ -1,0 +1,351 @@
+// zgpu_lz_sorted.hip -- LZ77 stage for levels 4-9, second parallel form: hash buckets as sorted arrays.
+//
+// Same mathematics as zgpu_lz_parallel.hip (static chains, all-position search with two budgets, record-driven lazy
+// parse -- SURVEY.md 8a A4/A5), different data structure.  Instead of walking `link(p)` pointers through an LDS ring, the
+// positions of a chunk are counting-sorted by their 3-byte hash:
+//
+//     S[start(h) .. start(h)+count(h))  = the positions with hash h, ascending
+//     idx(p)   = index of p in S,   rank(p) = number of earlier positions with the same hash
+//
+// so the hash chain of p, nearest candidate first, is simply S[idx-1], S[idx-2], ... S[idx-rank]: no dependent pointer
+// hop per candidate (the next candidates are known in advance and are fetched four at a time with one 8-byte load), no
+// link ring in LDS (the match kernel needs only the 64 KiB chunk there, so two 1024-lane workgroups fit a CU instead
+// of one), no tiles and no per-tile barriers (any position can be searched at any time).
+//
+//   K1' sort_kernel    one wave per chunk: rank(p) by a sequential pass over count[h] in LDS (64 positions per step,
+//                      duplicates inside a step resolved with ballots), exclusive scan of the counts, scatter to S.
+//   K2' match2_kernel  one 1024-lane workgroup per chunk, lanes = positions, the state machine of zgpu_lz_parallel.hip
+//                      with rounds of four candidates.
+//   K3                 parse_kernel of zgpu_lz_parallel.hip, unchanged (same record format).
+#include "zgpu_common.h"
+#include "../../include/zamd_gpu.h"
+
+namespace zgpu {
+
+void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
+void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
+void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+
+constexpr uint32_t kSuperS = 1024;   // positions per superblock of the sort passes
+constexpr uint32_t kSPad = 8;        // u16 entries in front of every chunk's S (group loads may reach below index 0)
+constexpr uint32_t kSStride = kChunkMax + kSPad;
+
+// per-chunk workspace layout (bytes): S | rank | idx | records
+size_t lz_sorted_workspace_bytes(uint32_t batch) { return (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kChunkMax * 2 + kChunkMax * 8) + 1024; }
+
+// ------------------------------------------------------------------------------------------------- K1'
+__global__ void __launch_bounds__(64) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint16_t *__restrict__ idx_all)
+{
+    __shared__ uint16_t cnt[kHashSize];                                         // counts, then bucket starts
+    __shared__ __attribute__((aligned(16))) uint32_t in_stage[kSuperS / 4 + 4]; // 1 KiB of input + 8 bytes of the next
+    __shared__ __attribute__((aligned(16))) uint16_t out_stage[kSuperS];
+    __shared__ uint8_t tag[4096];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax, *ix = idx_all + (size_t)c * kChunkMax;
+    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+    const uint32_t npos = n >= 3 ? n - 2 : 0;
+    volatile uint16_t *vcnt = cnt;
+    volatile uint8_t *vtag = tag;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    auto fetch = [&](uint32_t sb) -> uint4 {
+        const uint32_t a = sb * kSuperS + lane * 16;
+        if (a + 16 <= n && aligned) return *reinterpret_cast<const uint4 *>(src + a);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < 16; k++) if (a + k < n) w[k >> 2] |= (uint32_t)src[a + k] << (8 * (k & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    auto flush16 = [&](uint16_t *dst_base, uint32_t sb) { // out_stage -> global, 32 bytes per lane
+        const uint32_t p0 = sb * kSuperS + lane * 16;
+        const uint4 *ls = reinterpret_cast<const uint4 *>(out_stage);
+        if (p0 + 16 <= n) { uint4 *dst = reinterpret_cast<uint4 *>(dst_base + p0); dst[0] = ls[lane * 2]; dst[1] = ls[lane * 2 + 1]; }
+        else for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) dst_base[p0 + k] = out_stage[lane * 16 + k];
+    };
+    const uint32_t nsuper = (n + kSuperS - 1) / kSuperS;
+    const uint8_t *s8 = reinterpret_cast<const uint8_t *>(in_stage);
+
+    // ---- pass A: rank(p) = number of earlier positions with the same hash ----
+    uint4 cur = fetch(0), nxt = fetch(1);
+    __syncthreads();
+    for (uint32_t sb = 0; sb < nsuper; sb++) {
+        reinterpret_cast<uint4 *>(in_stage)[lane] = cur;
+        if (lane == 0) { in_stage[kSuperS / 4] = nxt.x; in_stage[kSuperS / 4 + 1] = nxt.y; }
+        if (sb > 0) flush16(rk, sb - 1);
+        cur = nxt; nxt = fetch(sb + 2);
+        __syncthreads();
+        const uint32_t base_p = sb * kSuperS;
+#pragma unroll 1
+        for (uint32_t st = 0; st < kSuperS / 64; st++) {
+            const uint32_t o = st * 64 + lane, p = base_p + o;
+            const bool live = p < npos;
+            uint32_t h = 0, old = 0;
+            if (live) { h = hash3(s8[o], s8[o + 1], s8[o + 2]); old = vcnt[h]; }
+            // lanes of this step that share a hash: detected through a small tag table (a false alarm is harmless)
+            if (live) vtag[h & 4095] = (uint8_t)lane;
+            const uint32_t seen = live ? (uint32_t)vtag[h & 4095] : lane;
+            unsigned long long clash = __ballot(live && seen != lane);
+            uint32_t rank = old, group = 1;
+            bool last = live;
+            while (clash) {
+                const int f = __ffsll((long long)clash) - 1;
+                const uint32_t h0 = __builtin_amdgcn_readlane(h, f);
+                const unsigned long long grp = __ballot(live && h == h0);
+                if (live && h == h0) {
+                    rank = old + (uint32_t)__popcll(grp & lt_mask);
+                    group = (uint32_t)__popcll(grp);
+                    last = (grp >> lane) == 1ull;
+                }
+                clash &= ~grp;
+            }
+            if (live && last) vcnt[h] = (uint16_t)(old + group);
+            out_stage[o] = (uint16_t)(live ? rank : 0);
+        }
+        __syncthreads();
+    }
+    if (nsuper) { const uint32_t p0 = (nsuper - 1) * kSuperS + lane * 16; for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) rk[p0 + k] = out_stage[lane * 16 + k]; }
+    __syncthreads();
+
+    // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place) ----
+    {
+        uint32_t carry = 0;
+        for (uint32_t i = 0; i < kHashSize / 64; i++) {
+            const uint32_t v = cnt[i * 64 + lane];
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+            cnt[i * 64 + lane] = (uint16_t)(carry + x - v);
+            carry += __shfl(x, 63);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass C: idx(p) = start(hash) + rank(p);  S[idx] = p ----
+    cur = fetch(0); nxt = fetch(1);
+    for (uint32_t sb = 0; sb < nsuper; sb++) {
+        reinterpret_cast<uint4 *>(in_stage)[lane] = cur;
+        if (lane == 0) { in_stage[kSuperS / 4] = nxt.x; in_stage[kSuperS / 4 + 1] = nxt.y; }
+        if (sb > 0) flush16(ix, sb - 1);
+        cur = nxt; nxt = fetch(sb + 2);
+        __syncthreads();
+        const uint32_t base_p = sb * kSuperS;
+#pragma unroll 4
+        for (uint32_t st = 0; st < kSuperS / 64; st++) {
+            const uint32_t o = st * 64 + lane, p = base_p + o;
+            uint32_t id = 0;
+            if (p < npos) {
+                const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]);
+                id = (uint32_t)cnt[h] + rk[p];
+                S[id] = (uint16_t)p;
+            }
+            out_stage[o] = (uint16_t)id;
+        }
+        __syncthreads();
+    }
+    if (nsuper) { const uint32_t p0 = (nsuper - 1) * kSuperS + lane * 16; for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) ix[p0 + k] = out_stage[lane * 16 + k]; }
+}
+
+// ------------------------------------------------------------------------------------------------- K2'
+__device__ inline uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+__device__ inline uint32_t lds_ld32u(uint32_t a) // 4 bytes at any LDS byte offset: aligned ds_read2_b32 + v_alignbyte
+{
+    uint64_t v; const uint32_t al = a & ~3u;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(al) : "memory");
+    return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3);
+}
+__device__ inline void lds_ld2bytes(uint32_t a, uint32_t &b0, uint32_t &b1)
+{
+    asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(a) : "memory");
+}
+__device__ inline uint64_t gload64u(const uint16_t *p) // 8 bytes at 2-byte alignment (gfx950 serves it, scripts/micro/global_unaligned.hip)
+{
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+struct __attribute__((packed, aligned(2))) U64u { uint64_t v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950
+__device__ inline void lds_ld8bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t (&b)[8])
+{
+    asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %9\n\tds_read_u8 %3, %9 offset:1\n\t"
+                 "ds_read_u8 %4, %10\n\tds_read_u8 %5, %10 offset:1\n\tds_read_u8 %6, %11\n\tds_read_u8 %7, %11 offset:1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+
+enum : uint32_t { sIdle = 0, sWalk = 1, sCmp = 2, sDone = 3 };
+constexpr uint32_t kM2Threads = 1024;
+
+__global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ rank_all,
+                                                               const uint16_t *__restrict__ idx_all, uint2 *__restrict__ recs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *d32 = lds;                                  // 65536 + 64 bytes of chunk data
+    uint32_t *work_next = lds + (kChunkMax + 64) / 4;     // next unassigned position of the chunk
+    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax, *ix = idx_all + (size_t)c * kChunkMax;
+    uint2 *rec = recs + (size_t)c * kChunkMax;
+    const uint32_t base = chunk_base(g, c);
+
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 *s128 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d128 = reinterpret_cast<uint4 *>(d32);
+        const uint32_t nv = n >> 4;
+        for (uint32_t i = tid; i < (kChunkMax + 64) / 16; i += kM2Threads) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < nv) v = s128[i];
+            else if (i == nv) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < (n & 15); k++) w[k >> 2] |= (uint32_t)src[(nv << 4) + k] << (8 * (k & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            d128[i] = v;
+        }
+    } else {
+        for (uint32_t i = tid; i < (kChunkMax + 64) / 4; i += kM2Threads) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < 4; k++) { uint32_t a = (i << 2) + k; if (a < n) v |= (uint32_t)src[a] << (8 * (k & 3)); }
+            d32[i] = v;
+        }
+    }
+    if (tid == 0) *work_next = 0;
+    __syncthreads();
+
+    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32);
+    // per-lane walk state
+    uint32_t mode = sIdle, p = 0, k = 0, avail = 0, best = 0, bestq = 0, snap_best = 0, snap_q = 0, l = 0, cap = 0, nice = 0, flags = 0, scan2 = 0, q = 0;
+    int thr = 0;          // a candidate q is usable iff (int)q >= thr; thr rises by one after the first candidate (deflate.c:1588-1589 vs 1163)
+    int thr_next = 0;
+    uint64_t cq = 0;      // up to four candidates, next one in the top 16 bits
+    const uint16_t *sp = S; // &S[idx]: candidate k is sp[-1-k]
+    uint32_t sup_next = 0, sup_end = 0;
+    bool dry = false;
+
+    for (;;) {
+        const uint32_t nw = (uint32_t)__popcll(__ballot(mode == sWalk)), nc = (uint32_t)__popcll(__ballot(mode == sCmp)), nfree = 64 - nw - nc;
+
+        // ---- REFILL ----
+        if (nfree >= 16 || nw + nc == 0) {
+            if (mode == sDone) {
+                uint32_t full = best | ((p - bestq) << 9), snap = snap_best | ((p - snap_q) << 9);
+                if (best < kMinMatch) full = 0;
+                // the one position whose first candidate can sit at window index 32768 (NIL after the slide, deflate.c:1309-1312)
+                if (p + base == kWSize + kMaxDist && avail != 0 && (uint32_t)sp[-1] + base == kWSize) flags = 1;
+                if ((snap & 511) < kMinMatch) snap = 0;
+                rec[p] = make_uint2(full | ((uint32_t)d8[p] << 24), snap | (flags << 24));
+                mode = sIdle;
+            }
+            for (int round = 0; round < 4; round++) {
+                const unsigned long long idle = __ballot(mode == sIdle);
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                if (nidle == 0) break;
+                if (sup_next == sup_end && !dry) {
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(work_next, 256u);
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    if (got >= n) dry = true;
+                    else { sup_next = got; sup_end = got + 256 < n ? got + 256 : n; }
+                }
+                if (sup_next == sup_end) break;
+                if (mode == sIdle) {
+                    const uint32_t np = sup_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
+                    if (np < sup_end) {
+                        p = np;
+                        const uint32_t look = n - np;
+                        cap = look < kMaxMatch ? look : kMaxMatch;
+                        nice = cfg.nice < look ? cfg.nice : look;
+                        const int w = (int)(np + base);
+                        const int t_first = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;  // first candidate: dist <= MAX_DIST, not NIL
+                        const int t_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
+                        thr = t_first; thr_next = t_next;
+                        const uint32_t rank = look >= kMinMatch ? rk[np] : 0;
+                        avail = rank < chainF ? rank : chainF;
+                        k = 0; best = kMinMatch - 1; bestq = np; snap_best = 0; snap_q = np; flags = 0;
+                        scan2 = (uint32_t)d8[np + 1] | ((uint32_t)d8[np + 2] << 8);
+                        if (avail) { sp = S + ix[np]; mode = sWalk; }
+                        else rec[np] = make_uint2((uint32_t)d8[np] << 24, 0); // no candidate at all
+                    }
+                }
+                const uint32_t take = nidle < sup_end - sup_next ? nidle : sup_end - sup_next;
+                sup_next += take;
+            }
+            if (__ballot(mode == sWalk || mode == sCmp) == 0) {
+                if (dry && sup_next == sup_end) break;
+                continue;
+            }
+        }
+
+        // ---- COMPARE ----
+        if (nc >= 16 || (nc > 0 && nw < 16)) {
+            while (__ballot(mode == sCmp)) {
+                if (mode == sCmp) {
+                    const uint32_t x = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + p + l);
+                    if (x == 0 && l + 4 < cap) l += 4;
+                    else {
+                        uint32_t len = x ? l + ((uint32_t)__builtin_ctz(x) >> 3) : l + 4;
+                        len = len < cap ? len : cap;
+                        if (len > best) {
+                            best = len; bestq = q; scan2 = (uint32_t)d8[p + len - 1] | ((uint32_t)d8[p + len] << 8);
+                            if (k < chainQ) { snap_best = len; snap_q = q; } // candidate number k+1 is within the quarter budget
+                        }
+                        k++;
+                        mode = (best >= nice || k >= avail) ? sDone : sWalk;
+                    }
+                }
+            }
+        }
+
+        // ---- WALK: rounds of up to four candidates (one 8-byte load of S per group of four) ----
+        if (mode == sWalk && (k & 3) == 0) cq = gload64u(sp - 4 - k);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (mode == sWalk) {
+                q = (uint32_t)(cq >> 48);
+                if ((int)q < thr) mode = sDone; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
+                else {
+                    thr = thr_next;
+                    uint32_t b0, b1;
+                    lds_ld2bytes(dbase + q + best - 1, b0, b1);
+                    cq <<= 16;
+                    if ((b0 | (b1 << 8)) == scan2) { mode = sCmp; l = 0; } // candidate may be longer than best: compare in full
+                    else {
+                        k++;
+                        if (k >= avail) mode = sDone;
+                        else if ((k & 3) == 0) break; // the next group of candidates is fetched at the top of the next round
+                    }
+                }
+            }
+        }
+    }
+}
+
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)
+{
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    const size_t nch = g.nchunks;
+    uint16_t *S = reinterpret_cast<uint16_t *>(w);
+    uint16_t *rk = reinterpret_cast<uint16_t *>(w + ((nch * kSStride * 2 + 255) & ~(size_t)255));
+    uint16_t *ix = rk + nch * kChunkMax;
+    uint2 *recs = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(ix + nch * kChunkMax));
+    hipEvent_t ev{};
+    prof_span_begin(prof, st, &ev);
+    hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(64), 0, st, g, S, rk, ix);
+    prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
+    prof_span_begin(prof, st, &ev);
+    const size_t lds_bytes = (kChunkMax + 64) + 64 + 320; // slack: speculative quick-reject reads may reach 258 bytes past a garbage candidate
+    static bool opt_in = false;
+    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(match2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); opt_in = true; }
+    hipLaunchKernelGGL(match2_kernel, dim3(g.nchunks), dim3(kM2Threads), lds_bytes, st, g, cfg, S, rk, ix, recs);
+    prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+    prof_span_begin(prof, st, &ev);
+    launch_parse(g, cfg, recs, tokens, meta, st);
+    prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
+}
+
+} // namespace zgpu
