@@ -167,7 +167,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
     const LevelCfg cfg = level_cfg(p->level);
     int impl = p->lz_impl;
-    if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_PARALLEL : ZGPU_LZ_SERIAL;
+    if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_SORTED : ZGPU_LZ_SERIAL;
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");

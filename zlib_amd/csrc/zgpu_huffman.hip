@@ -21,7 +21,10 @@
 
 namespace zgpu {
 
-constexpr int kThreads = 256;
+#ifndef ZGPU_HUFF_THREADS
+#define ZGPU_HUFF_THREADS 128
+#endif
+constexpr int kThreads = ZGPU_HUFF_THREADS;
 
 struct TreeWork {
     uint16_t freq[kHeapSize];
@@ -198,7 +201,9 @@ __device__ inline uint32_t block_reduce_add(uint32_t v, uint32_t *tmp)
     __syncthreads();
     if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
     __syncthreads();
-    return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    uint32_t s = 0;
+    for (int w = 0; w < kThreads / 64; w++) s += tmp[w];
+    return s;
 }
 
 // exclusive prefix sum over the 256 lanes; *total receives the sum
@@ -211,7 +216,9 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < wave; w++) base += tmp[w];
-    *total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    uint32_t s = 0;
+    for (int w = 0; w < kThreads / 64; w++) s += tmp[w];
+    *total = s;
     return base + x - v;
 }
 

@@ -34,56 +34,69 @@ constexpr uint32_t kSStride = kChunkMax + kSPad;
 size_t lz_sorted_workspace_bytes(uint32_t batch) { return (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kChunkMax * 2 + kChunkMax * 8) + 1024; }
 
 // ------------------------------------------------------------------------------------------------- K1'
-__global__ void __launch_bounds__(64) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint16_t *__restrict__ idx_all)
+// One 256-lane workgroup (4 waves) per chunk.  Pass A is sequential in position order only among positions that share a
+// hash, so the hash space is split four ways: every wave sweeps all positions but counts only the hashes with
+// (h & 3) == its wave number -- four sequential sweeps run side by side on the four SIMDs with a quarter of the
+// duplicate-resolution work each.  Passes B and C are plainly parallel over the 256 lanes.
+#ifndef ZGPU_SORT_WAVES
+#define ZGPU_SORT_WAVES 8
+#endif
+constexpr uint32_t kSortWaves = ZGPU_SORT_WAVES, kSortThreads = 64 * kSortWaves; // waves per chunk: 4 or 8 (or 16)
+
+__global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint16_t *__restrict__ idx_all)
 {
     __shared__ uint16_t cnt[kHashSize];                                         // counts, then bucket starts
     __shared__ __attribute__((aligned(16))) uint32_t in_stage[kSuperS / 4 + 4]; // 1 KiB of input + 8 bytes of the next
     __shared__ __attribute__((aligned(16))) uint16_t out_stage[kSuperS];
     __shared__ uint8_t tag[4096];
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint32_t wave_tot[kSortWaves];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax, *ix = idx_all + (size_t)c * kChunkMax;
-    for (uint32_t i = lane; i < kHashSize / 2; i += 64) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+    for (uint32_t i = tid; i < kHashSize / 2; i += kSortThreads) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
     volatile uint16_t *vcnt = cnt;
     volatile uint8_t *vtag = tag;
     const unsigned long long lt_mask = (1ull << lane) - 1;
-    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-    auto fetch = [&](uint32_t sb) -> uint4 {
-        const uint32_t a = sb * kSuperS + lane * 16;
-        if (a + 16 <= n && aligned) return *reinterpret_cast<const uint4 *>(src + a);
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (uint32_t k = 0; k < 16; k++) if (a + k < n) w[k >> 2] |= (uint32_t)src[a + k] << (8 * (k & 3));
-        return make_uint4(w[0], w[1], w[2], w[3]);
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    auto fetch = [&](uint32_t sb) -> uint32_t { // dword `tid` of superblock sb (threads 0..255), zero padded past n
+        if (tid >= kSuperS / 4) return 0;
+        const uint32_t a = sb * kSuperS + tid * 4;
+        if (a + 4 <= n && aligned) return *reinterpret_cast<const uint32_t *>(src + a);
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; k++) if (a + k < n) v |= (uint32_t)src[a + k] << (8 * k);
+        return v;
     };
-    auto flush16 = [&](uint16_t *dst_base, uint32_t sb) { // out_stage -> global, 32 bytes per lane
-        const uint32_t p0 = sb * kSuperS + lane * 16;
-        const uint4 *ls = reinterpret_cast<const uint4 *>(out_stage);
-        if (p0 + 16 <= n) { uint4 *dst = reinterpret_cast<uint4 *>(dst_base + p0); dst[0] = ls[lane * 2]; dst[1] = ls[lane * 2 + 1]; }
-        else for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) dst_base[p0 + k] = out_stage[lane * 16 + k];
+    auto flush = [&](uint16_t *dst_base, uint32_t sb) { // out_stage -> global, 8 bytes per lane (threads 0..255)
+        if (tid >= kSuperS / 4) return;
+        const uint32_t p0 = sb * kSuperS + tid * 4;
+        if (p0 + 4 <= n) *reinterpret_cast<uint2 *>(dst_base + p0) = reinterpret_cast<const uint2 *>(out_stage)[tid];
+        else for (uint32_t k = 0; k < 4; k++) if (p0 + k < n) dst_base[p0 + k] = out_stage[tid * 4 + k];
     };
     const uint32_t nsuper = (n + kSuperS - 1) / kSuperS;
     const uint8_t *s8 = reinterpret_cast<const uint8_t *>(in_stage);
 
     // ---- pass A: rank(p) = number of earlier positions with the same hash ----
-    uint4 cur = fetch(0), nxt = fetch(1);
+    uint32_t cur = fetch(0), nxt = fetch(1);
     __syncthreads();
     for (uint32_t sb = 0; sb < nsuper; sb++) {
-        reinterpret_cast<uint4 *>(in_stage)[lane] = cur;
-        if (lane == 0) { in_stage[kSuperS / 4] = nxt.x; in_stage[kSuperS / 4 + 1] = nxt.y; }
-        if (sb > 0) flush16(rk, sb - 1);
+        if (tid < kSuperS / 4) in_stage[tid] = cur;
+        if (tid < 2) in_stage[kSuperS / 4 + tid] = __shfl(nxt, tid);
+        if (sb > 0) flush(rk, sb - 1);
         cur = nxt; nxt = fetch(sb + 2);
         __syncthreads();
         const uint32_t base_p = sb * kSuperS;
 #pragma unroll 1
         for (uint32_t st = 0; st < kSuperS / 64; st++) {
             const uint32_t o = st * 64 + lane, p = base_p + o;
-            const bool live = p < npos;
-            uint32_t h = 0, old = 0;
-            if (live) { h = hash3(s8[o], s8[o + 1], s8[o + 2]); old = vcnt[h]; }
-            // lanes of this step that share a hash: detected through a small tag table (a false alarm is harmless)
+            const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]);
+            const bool live = p < npos && (h & (kSortWaves - 1)) == wave; // this wave owns its share of the hash space
+            uint32_t old = 0;
+            if (live) old = vcnt[h];
+            // lanes of this step that share a hash: detected through a small tag table (a false alarm is harmless; the
+            // index keeps the two ownership bits, so waves never touch each other's tags)
             if (live) vtag[h & 4095] = (uint8_t)lane;
             const uint32_t seen = live ? (uint32_t)vtag[h & 4095] : lane;
             unsigned long long clash = __ballot(live && seen != lane);
@@ -101,39 +114,42 @@ __global__ void __launch_bounds__(64) sort_kernel(ChunkGeom g, uint16_t *__restr
                 clash &= ~grp;
             }
             if (live && last) vcnt[h] = (uint16_t)(old + group);
-            out_stage[o] = (uint16_t)(live ? rank : 0);
+            if (live) out_stage[o] = (uint16_t)rank;
+            else if (p >= npos && wave == 0) out_stage[o] = 0;
         }
         __syncthreads();
     }
-    if (nsuper) { const uint32_t p0 = (nsuper - 1) * kSuperS + lane * 16; for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) rk[p0 + k] = out_stage[lane * 16 + k]; }
+    if (nsuper && tid < kSuperS / 4) { const uint32_t p0 = (nsuper - 1) * kSuperS + tid * 4; for (uint32_t k = 0; k < 4; k++) if (p0 + k < n) rk[p0 + k] = out_stage[tid * 4 + k]; }
     __syncthreads();
 
-    // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place) ----
+    // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place), 128 consecutive counts per lane ----
     {
-        uint32_t carry = 0;
-        for (uint32_t i = 0; i < kHashSize / 64; i++) {
-            const uint32_t v = cnt[i * 64 + lane];
-            uint32_t x = v;
+        const uint32_t per = kHashSize / kSortThreads;
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < per; i++) sum += cnt[tid * per + i];
+        uint32_t x = sum;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
-            cnt[i * 64 + lane] = (uint16_t)(carry + x - v);
-            carry += __shfl(x, 63);
-        }
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        uint32_t basev = x - sum;
+        for (uint32_t w = 0; w < wave; w++) basev += wave_tot[w];
+        for (uint32_t i = 0; i < per; i++) { const uint32_t v = cnt[tid * per + i]; cnt[tid * per + i] = (uint16_t)basev; basev += v; }
     }
     __syncthreads();
 
     // ---- pass C: idx(p) = start(hash) + rank(p);  S[idx] = p ----
     cur = fetch(0); nxt = fetch(1);
     for (uint32_t sb = 0; sb < nsuper; sb++) {
-        reinterpret_cast<uint4 *>(in_stage)[lane] = cur;
-        if (lane == 0) { in_stage[kSuperS / 4] = nxt.x; in_stage[kSuperS / 4 + 1] = nxt.y; }
-        if (sb > 0) flush16(ix, sb - 1);
+        if (tid < kSuperS / 4) in_stage[tid] = cur;
+        if (tid < 2) in_stage[kSuperS / 4 + tid] = __shfl(nxt, tid);
+        if (sb > 0) flush(ix, sb - 1);
         cur = nxt; nxt = fetch(sb + 2);
         __syncthreads();
         const uint32_t base_p = sb * kSuperS;
-#pragma unroll 4
-        for (uint32_t st = 0; st < kSuperS / 64; st++) {
-            const uint32_t o = st * 64 + lane, p = base_p + o;
+#pragma unroll
+        for (uint32_t st = 0; st < kSuperS / kSortThreads; st++) {
+            const uint32_t o = st * kSortThreads + tid, p = base_p + o;
             uint32_t id = 0;
             if (p < npos) {
                 const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]);
@@ -144,7 +160,7 @@ __global__ void __launch_bounds__(64) sort_kernel(ChunkGeom g, uint16_t *__restr
         }
         __syncthreads();
     }
-    if (nsuper) { const uint32_t p0 = (nsuper - 1) * kSuperS + lane * 16; for (uint32_t k = 0; k < 16; k++) if (p0 + k < n) ix[p0 + k] = out_stage[lane * 16 + k]; }
+    if (nsuper && tid < kSuperS / 4) { const uint32_t p0 = (nsuper - 1) * kSuperS + tid * 4; for (uint32_t k = 0; k < 4; k++) if (p0 + k < n) ix[p0 + k] = out_stage[tid * 4 + k]; }
 }
 
 // ------------------------------------------------------------------------------------------------- K2'
@@ -177,6 +193,15 @@ __device__ inline void lds_ld8bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint3
 
 enum : uint32_t { sIdle = 0, sWalk = 1, sCmp = 2, sDone = 3 };
 constexpr uint32_t kM2Threads = 1024;
+#ifndef ZGPU_M2_REFILL
+#define ZGPU_M2_REFILL 16
+#endif
+#ifndef ZGPU_M2_CMP
+#define ZGPU_M2_CMP 16
+#endif
+#ifndef ZGPU_M2_ROUNDS
+#define ZGPU_M2_ROUNDS 1
+#endif
 
 __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ rank_all,
                                                                const uint16_t *__restrict__ idx_all, uint2 *__restrict__ recs)
@@ -231,7 +256,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
         const uint32_t nw = (uint32_t)__popcll(__ballot(mode == sWalk)), nc = (uint32_t)__popcll(__ballot(mode == sCmp)), nfree = 64 - nw - nc;
 
         // ---- REFILL ----
-        if (nfree >= 16 || nw + nc == 0) {
+        if (nfree >= ZGPU_M2_REFILL || nw + nc == 0) {
             if (mode == sDone) {
                 uint32_t full = best | ((p - bestq) << 9), snap = snap_best | ((p - snap_q) << 9);
                 if (best < kMinMatch) full = 0;
@@ -282,7 +307,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
         }
 
         // ---- COMPARE ----
-        if (nc >= 16 || (nc > 0 && nw < 16)) {
+        if (nc >= ZGPU_M2_CMP || (nc > 0 && nw < 16)) {
             while (__ballot(mode == sCmp)) {
                 if (mode == sCmp) {
                     const uint32_t x = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + p + l);
@@ -302,6 +327,8 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
         }
 
         // ---- WALK: rounds of up to four candidates (one 8-byte load of S per group of four) ----
+#pragma unroll 1
+        for (int rnd = 0; rnd < ZGPU_M2_ROUNDS; rnd++) {
         if (mode == sWalk && (k & 3) == 0) cq = gload64u(sp - 4 - k);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -322,6 +349,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
                 }
             }
         }
+        }
     }
 }
 
@@ -335,7 +363,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     uint2 *recs = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(ix + nch * kChunkMax));
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
-    hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(64), 0, st, g, S, rk, ix);
+    hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, ix);
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
     const size_t lds_bytes = (kChunkMax + 64) + 64 + 320; // slack: speculative quick-reject reads may reach 258 bytes past a garbage candidate
