@@ -143,24 +143,20 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
     for (uint32_t sb = 0; sb < nsuper; sb++) {
         if (tid < kSuperS / 4) in_stage[tid] = cur;
         if (tid < 2) in_stage[kSuperS / 4 + tid] = __shfl(nxt, tid);
-        if (sb > 0) flush(ix, sb - 1);
         cur = nxt; nxt = fetch(sb + 2);
         __syncthreads();
         const uint32_t base_p = sb * kSuperS;
 #pragma unroll
         for (uint32_t st = 0; st < kSuperS / kSortThreads; st++) {
             const uint32_t o = st * kSortThreads + tid, p = base_p + o;
-            uint32_t id = 0;
             if (p < npos) {
-                const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]);
-                id = (uint32_t)cnt[h] + rk[p];
+                const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]), r = rk[p], id = (uint32_t)cnt[h] + r;
                 S[id] = (uint16_t)p;
+                ix[id] = (uint16_t)r; // rank in S order: the match kernel walks S, not the positions
             }
-            out_stage[o] = (uint16_t)id;
         }
         __syncthreads();
     }
-    if (nsuper && tid < kSuperS / 4) { const uint32_t p0 = (nsuper - 1) * kSuperS + tid * 4; for (uint32_t k = 0; k < 4; k++) if (p0 + k < n) ix[p0 + k] = out_stage[tid * 4 + k]; }
 }
 
 // ------------------------------------------------------------------------------------------------- K2'
@@ -214,8 +210,10 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
-    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax, *ix = idx_all + (size_t)c * kChunkMax;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
+    (void)rank_all;
     uint2 *rec = recs + (size_t)c * kChunkMax;
+    const uint32_t npos = n >= 3 ? n - 2 : 0;
     const uint32_t base = chunk_base(g, c);
 
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -240,6 +238,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
         }
     }
     if (tid == 0) *work_next = 0;
+    for (uint32_t q2 = npos + tid; q2 < n; q2 += kM2Threads) rec[q2] = make_uint2((uint32_t)src[q2] << 24, 0); // the last two positions carry no hash
     __syncthreads();
 
     const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32);
@@ -274,13 +273,16 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
                     uint32_t got = 0;
                     if (lane == 0) got = atomicAdd(work_next, 256u);
                     got = __builtin_amdgcn_readfirstlane(got);
-                    if (got >= n) dry = true;
-                    else { sup_next = got; sup_end = got + 256 < n ? got + 256 : n; }
+                    if (got >= npos) dry = true;
+                    else { sup_next = got; sup_end = got + 256 < npos ? got + 256 : npos; }
                 }
                 if (sup_next == sup_end) break;
                 if (mode == sIdle) {
-                    const uint32_t np = sup_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
-                    if (np < sup_end) {
+                    // work items are indices into S: neighbouring lanes get neighbouring entries of one hash bucket, i.e. chains
+                    // of almost equal length (lane balance) that overlap in memory (the 8-byte candidate loads hit in cache)
+                    const uint32_t wi = sup_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
+                    if (wi < sup_end) {
+                        const uint32_t np = S[wi];
                         p = np;
                         const uint32_t look = n - np;
                         cap = look < kMaxMatch ? look : kMaxMatch;
@@ -289,11 +291,11 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
                         const int t_first = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;  // first candidate: dist <= MAX_DIST, not NIL
                         const int t_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
                         thr = t_first; thr_next = t_next;
-                        const uint32_t rank = look >= kMinMatch ? rk[np] : 0;
+                        const uint32_t rank = rkS[wi];
                         avail = rank < chainF ? rank : chainF;
                         k = 0; best = kMinMatch - 1; bestq = np; snap_best = 0; snap_q = np; flags = 0;
                         scan2 = (uint32_t)d8[np + 1] | ((uint32_t)d8[np + 2] << 8);
-                        if (avail) { sp = S + ix[np]; mode = sWalk; }
+                        if (avail) { sp = S + wi; mode = sWalk; }
                         else rec[np] = make_uint2((uint32_t)d8[np] << 24, 0); // no candidate at all
                     }
                 }
