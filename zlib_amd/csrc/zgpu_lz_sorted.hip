@@ -18,6 +18,7 @@
 //                      with rounds of four candidates.
 //   K3                 parse_kernel of zgpu_lz_parallel.hip, unchanged (same record format).
 #include "zgpu_common.h"
+#include <cstdlib>
 #include "../../include/zamd_gpu.h"
 
 namespace zgpu {
@@ -199,23 +200,9 @@ constexpr uint32_t kM2Threads = 1024;
 #define ZGPU_M2_ROUNDS 1
 #endif
 
-__global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ rank_all,
-                                                               const uint16_t *__restrict__ idx_all, uint2 *__restrict__ recs)
+// chunk bytes -> LDS (zero padded to kChunkMax + 64), by all kM2Threads lanes of the workgroup
+__device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32, uint32_t tid)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *d32 = lds;                                  // 65536 + 64 bytes of chunk data
-    uint32_t *work_next = lds + (kChunkMax + 64) / 4;     // next unassigned position of the chunk
-    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
-    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    uint64_t lo; uint32_t n;
-    chunk_span(g, c, lo, n);
-    const uint8_t *src = g.in + lo;
-    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
-    (void)rank_all;
-    uint2 *rec = recs + (size_t)c * kChunkMax;
-    const uint32_t npos = n >= 3 ? n - 2 : 0;
-    const uint32_t base = chunk_base(g, c);
-
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const uint4 *s128 = reinterpret_cast<const uint4 *>(src);
         uint4 *d128 = reinterpret_cast<uint4 *>(d32);
@@ -237,6 +224,26 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
             d32[i] = v;
         }
     }
+}
+
+__global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ rank_all,
+                                                               const uint16_t *__restrict__ idx_all, uint2 *__restrict__ recs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *d32 = lds;                                  // 65536 + 64 bytes of chunk data
+    uint32_t *work_next = lds + (kChunkMax + 64) / 4;     // next unassigned position of the chunk
+    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
+    (void)rank_all;
+    uint2 *rec = recs + (size_t)c * kChunkMax;
+    const uint32_t npos = n >= 3 ? n - 2 : 0;
+    const uint32_t base = chunk_base(g, c);
+
+    stage_chunk(src, n, d32, tid);
     if (tid == 0) *work_next = 0;
     for (uint32_t q2 = npos + tid; q2 < n; q2 += kM2Threads) rec[q2] = make_uint2((uint32_t)src[q2] << 24, 0); // the last two positions carry no hash
     __syncthreads();
@@ -355,6 +362,169 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
     }
 }
 
+// ------------------------------------------------------------------------------------------------- K2''
+// Lockstep form of the same search.  A wave takes 64 CONSECUTIVE entries of S (one work item = one block of 64 S
+// indices); lane L searches position S[wi], wi = 64*blk + L, and all lanes examine their k-th candidate S[wi-1-k] in the
+// same step.  Neighbouring entries of S belong to the same hash bucket, so their chains have (almost) the same length and
+// the candidate loads of a step are one contiguous, coalesced run of S.
+//
+// The full string comparison is taken out of the walk altogether.  longest_match's result has an order-free statement:
+// with len(k) = common prefix of the scan string and candidate k (capped by the lookahead), the walk ends at the FIRST k
+// with len(k) >= nice_match (deflate.c:1224) and returns that candidate; otherwise it returns the largest len(k), the
+// earliest k among equals (deflate.c:1198, strict >).  Both are the maximum of one integer key per candidate:
+//       len >= nice :  1<<31 | (4095-k)<<16 | len            len < nice :  len<<16 | (4095-k)
+// So a candidate that passes the two-byte quick check (deflate.c:1187-1190) is merely appended to a per-wave ring in LDS,
+// and whenever 64 of them have gathered, the 64 lanes compute 64 prefix lengths at full occupancy -- any lane serves any
+// owner -- and fold the keys into the owner's slot with an LDS atomic max.  The owners then read their slot back and walk
+// on with the new best length.  Walking with a stale (shorter) best length is exact: the quick check against it rejects
+// only candidates that match at most that many bytes, which can be neither an improvement nor a nice_match stop; and
+// whatever was appended after the stopping candidate loses against its key.  The quarter-budget result (deflate.c:1146)
+// is the slot as it stands once every candidate k < chain/4 has been folded.
+#ifndef ZGPU_M3_PERIOD
+#define ZGPU_M3_PERIOD 16 // steps between forced folds (keeps the walkers' best length fresh); a power of two <= 256
+#endif
+constexpr uint32_t kRing = 128;                                  // ring entries per wave: q | owner<<16 | (k&1023)<<22
+constexpr uint32_t kM3WaveLds = kRing * 4 + 64 * 4 + 64 * 2;     // ring + slots + owners' positions
+constexpr uint32_t kM3DataLds = kChunkMax + 64 + 320;            // chunk bytes + zero pad + slack for reads past a garbage candidate
+constexpr uint32_t kM3Lds = kM3DataLds + 16 + (kM2Threads / 64) * kM3WaveLds;
+
+// wave-private LDS words by byte offset (plain C++ volatile accesses through a generic pointer compile to flat_* memory instructions)
+__device__ inline void lds_st32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline void lds_st16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline void lds_max32(uint32_t a, uint32_t v) { asm volatile("ds_max_u32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline uint32_t lds_ld32(uint32_t a) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ inline uint32_t lds_ld16(uint32_t a) { uint32_t v; asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+
+__global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ idx_all,
+                                                               uint2 *__restrict__ recs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *d32 = lds;
+    uint32_t *work_next = lds + kM3DataLds / 4; // next unassigned block of S
+    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ring = lds_off(lds) + kM3DataLds + 16 + wave * kM3WaveLds, slot = ring + kRing * 4, pw = slot + 64 * 4; // LDS byte offsets
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
+    uint2 *rec = recs + (size_t)c * kChunkMax;
+    const uint32_t npos = n >= 3 ? n - 2 : 0;
+    const uint32_t base = chunk_base(g, c);
+    stage_chunk(src, n, d32, tid);
+    if (tid == 0) *work_next = 0;
+    for (uint32_t q2 = npos + tid; q2 < n; q2 += kM2Threads) rec[q2] = make_uint2((uint32_t)src[q2] << 24, 0); // the last two positions carry no hash
+    __syncthreads();
+
+    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = (npos + 63) >> 6;
+    for (;;) {
+        uint32_t blk = 0;
+        if (lane == 0) blk = atomicAdd(work_next, 1u);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= nblk) break;
+        const uint32_t wi = (blk << 6) + lane;
+        const bool valid = wi < npos;
+        uint32_t p = 0, avail = 0;
+        if (valid) { p = S[wi]; const uint32_t rank = rkS[wi]; avail = rank < chainF ? rank : chainF; }
+        const int w = (int)(p + base);
+        int thr = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;                 // first candidate: dist <= MAX_DIST, not NIL
+        const int thr_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
+        uint32_t best = kMinMatch - 1, key_seen = 0, snapkey = 0;
+        uint32_t scan2 = (uint32_t)d8[p + 1] | ((uint32_t)d8[p + 2] << 8);
+        uint32_t boff = dbase + best - 1;
+        bool active = avail != 0, snap_taken = false;
+        const uint16_t *sp = S + wi; // candidate k is sp[-1-k]
+        lds_st32(slot + lane * 4, 0);
+        lds_st16(pw + lane * 2, p);
+        uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
+        const uint32_t lanebits = lane << 16;
+
+        // fold up to 64 ring entries into their owners' slots, then let every owner pick up its new best length
+        auto fold = [&](uint32_t kcur) {
+            const uint32_t cnt = tail - head < 64 ? tail - head : 64;
+            if (lane < cnt) {
+                const uint32_t e = lds_ld32(ring + (((head + lane) & (kRing - 1)) << 2));
+                const uint32_t q = e & 0xffffu, o = (e >> 16) & 63u;
+                const uint32_t k = kcur - ((kcur - (e >> 22)) & 1023u);
+                const uint32_t po = lds_ld16(pw + o * 2), look = n - po, cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
+                uint32_t l = 0, x;
+                for (;;) {
+                    x = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + po + l);
+                    if (x != 0 || l + 4 >= cap) break;
+                    l += 4;
+                }
+                uint32_t len = x ? l + ((uint32_t)__builtin_ctz(x) >> 3) : l + 4;
+                len = len < cap ? len : cap;
+                if (len >= kMinMatch) {
+                    const uint32_t key = len >= nice ? (0x80000000u | ((4095u - k) << 16) | len) : ((len << 16) | (4095u - k));
+                    lds_max32(slot + o * 4, key);
+                }
+            }
+            head += cnt;
+            const uint32_t key = lds_ld32(slot + lane * 4);
+            if (key != key_seen) {
+                key_seen = key;
+                if (key >> 31) { best = key & 0x1ffu; active = false; }
+                else best = key >> 16;
+                boff = dbase + best - 1;
+                scan2 = (uint32_t)d8[p + best - 1] | ((uint32_t)d8[p + best] << 8);
+            }
+        };
+
+        uint64_t cq = 0;
+        if (active) cq = reinterpret_cast<const U64u *>(sp - 4)->v;
+        uint32_t k = 0;
+        for (;; k += 4) {
+            if (__ballot(active) == 0) break;
+            if (k == chainQ) {
+                while (tail != head) fold(k);
+                snapkey = key_seen; snap_taken = true;
+            } else if ((k & (ZGPU_M3_PERIOD - 1)) == 0 && tail != head) fold(k);
+            uint64_t cqn = 0;
+            if (active && k + 4 < avail) cqn = reinterpret_cast<const U64u *>(sp - 8 - k)->v;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                bool pass = false;
+                const uint32_t q = (uint32_t)(cq >> (48 - 16 * j)) & 0xffffu;
+                if (active) {
+                    if ((int)q < thr) active = false; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
+                    else {
+                        thr = thr_next;
+                        uint32_t b0, b1;
+                        lds_ld2bytes(boff + q, b0, b1);
+                        pass = (b0 | (b1 << 8)) == scan2;
+                    }
+                }
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    if (pass) lds_st32(ring + (((tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))) & (kRing - 1)) << 2), q | lanebits | ((k + j) << 22));
+                    tail += (uint32_t)__popcll(m);
+                    if (tail - head >= 64) fold(k + j);
+                }
+                if (k + j + 1 >= avail) active = false;
+            }
+            cq = cqn;
+        }
+        while (tail != head) fold(k);
+        if (!snap_taken) snapkey = key_seen;
+        if (valid) {
+            uint32_t full = 0, snap = 0, flags = 0;
+            if (key_seen) {
+                const uint32_t kb = 4095u - ((key_seen >> 31) ? (key_seen >> 16) & 0xfffu : key_seen & 0xfffu);
+                full = best | ((p - (uint32_t)sp[-1 - (int)kb]) << 9);
+            }
+            if (snapkey) {
+                const uint32_t ks = 4095u - ((snapkey >> 31) ? (snapkey >> 16) & 0xfffu : snapkey & 0xfffu);
+                const uint32_t sl = (snapkey >> 31) ? snapkey & 0x1ffu : snapkey >> 16;
+                snap = sl | ((p - (uint32_t)sp[-1 - (int)ks]) << 9);
+            }
+            // the one position whose first candidate can sit at window index 32768 (NIL after the slide, deflate.c:1309-1312)
+            if (p + base == kWSize + kMaxDist && avail != 0 && (uint32_t)sp[-1] + base == kWSize) flags = 1;
+            rec[p] = make_uint2(full | ((uint32_t)d8[p] << 24), snap | (flags << 24));
+        }
+    }
+}
+
 void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)
 {
     uint8_t *w = static_cast<uint8_t *>(workspace);
@@ -369,9 +539,13 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
     const size_t lds_bytes = (kChunkMax + 64) + 64 + 320; // slack: speculative quick-reject reads may reach 258 bytes past a garbage candidate
-    static bool opt_in = false;
+    static bool opt_in = false, opt_in3 = false;
     if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(match2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); opt_in = true; }
-    hipLaunchKernelGGL(match2_kernel, dim3(g.nchunks), dim3(kM2Threads), lds_bytes, st, g, cfg, S, rk, ix, recs);
+    static int impl = -1;
+    if (impl < 0) { const char *e = getenv("ZGPU_MATCH"); impl = e ? atoi(e) : 3; }
+    if (!opt_in3) { hipFuncSetAttribute(reinterpret_cast<const void *>(match3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kM3Lds); opt_in3 = true; }
+    if (impl == 2) hipLaunchKernelGGL(match2_kernel, dim3(g.nchunks), dim3(kM2Threads), lds_bytes, st, g, cfg, S, rk, ix, recs);
+    else hipLaunchKernelGGL(match3_kernel, dim3(g.nchunks), dim3(kM2Threads), kM3Lds, st, g, cfg, S, ix, recs);
     prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
     prof_span_begin(prof, st, &ev);
     launch_parse(g, cfg, recs, tokens, meta, st);
