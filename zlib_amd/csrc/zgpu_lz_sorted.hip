@@ -381,9 +381,21 @@ __global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, Leve
 // whatever was appended after the stopping candidate loses against its key.  The quarter-budget result (deflate.c:1146)
 // is the slot as it stands once every candidate k < chain/4 has been folded.
 #ifndef ZGPU_M3_PERIOD
-#define ZGPU_M3_PERIOD 16 // steps between forced folds (keeps the walkers' best length fresh); a power of two <= 256
+#define ZGPU_M3_PERIOD 32 // steps between forced folds (keeps the walkers' best length fresh); a power of two <= 256
 #endif
-constexpr uint32_t kRing = 128;                                  // ring entries per wave: q | owner<<16 | (k&1023)<<22
+#ifdef ZGPU_M3_STATS // debug build only (scripts/m3_stats.py): 0 wave-steps, 1 active lane-steps, 2 ring entries, 3 folds, 4 fold iterations, 5 positions
+__device__ unsigned long long m3_stats[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_m3_stats(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(m3_stats), sizeof z);
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(m3_stats), z, sizeof z);
+}
+#define M3_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&m3_stats[i], v_); } while (0)
+#else
+#define M3_STAT(i, v) do { } while (0)
+#endif
+constexpr uint32_t kRing = 128;                                  // parked candidates per wave: q | owner<<16 | (k&1023)<<22
 constexpr uint32_t kM3WaveLds = kRing * 4 + 64 * 4 + 64 * 2;     // ring + slots + owners' positions
 constexpr uint32_t kM3DataLds = kChunkMax + 64 + 320;            // chunk bytes + zero pad + slack for reads past a garbage candidate
 constexpr uint32_t kM3Lds = kM3DataLds + 16 + (kM2Threads / 64) * kM3WaveLds;
@@ -403,7 +415,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     uint32_t *work_next = lds + kM3DataLds / 4; // next unassigned block of S
     const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t ring = lds_off(lds) + kM3DataLds + 16 + wave * kM3WaveLds, slot = ring + kRing * 4, pw = slot + 64 * 4; // LDS byte offsets
+    const uint32_t ring = (uint32_t)__builtin_amdgcn_readfirstlane(lds_off(lds) + kM3DataLds + 16 + wave * kM3WaveLds), slot = ring + kRing * 4, pw = slot + 64 * 4; // LDS byte offsets
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
@@ -436,20 +448,24 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         const uint16_t *sp = S + wi; // candidate k is sp[-1-k]
         lds_st32(slot + lane * 4, 0);
         lds_st16(pw + lane * 2, p);
-        uint32_t head = 0, tail = 0; // ring indices (wave-uniform)
+        uint32_t tail = 0; // entries on the ring (wave-uniform)
         const uint32_t lanebits = lane << 16;
+        M3_STAT(5, __popcll(__builtin_amdgcn_ballot_w64(valid)));
 
         // fold up to 64 ring entries into their owners' slots, then let every owner pick up its new best length
         auto fold = [&](uint32_t kcur) {
-            const uint32_t cnt = tail - head < 64 ? tail - head : 64;
+            const uint32_t cnt = tail < 64 ? tail : 64;
+            M3_STAT(3, 1);
+            tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail - cnt); // the ring is a stack: any order of folding gives the same maxima
             if (lane < cnt) {
-                const uint32_t e = lds_ld32(ring + (((head + lane) & (kRing - 1)) << 2));
+                const uint32_t e = lds_ld32(ring + ((tail + lane) << 2));
                 const uint32_t q = e & 0xffffu, o = (e >> 16) & 63u;
                 const uint32_t k = kcur - ((kcur - (e >> 22)) & 1023u);
                 const uint32_t po = lds_ld16(pw + o * 2), look = n - po, cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
                 uint32_t l = 0, x;
                 for (;;) {
                     x = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + po + l);
+                    M3_STAT(4, 1); // (counts only the iterations lane 0 takes part in)
                     if (x != 0 || l + 4 >= cap) break;
                     l += 4;
                 }
@@ -460,7 +476,6 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
                     lds_max32(slot + o * 4, key);
                 }
             }
-            head += cnt;
             const uint32_t key = lds_ld32(slot + lane * 4);
             if (key != key_seen) {
                 key_seen = key;
@@ -475,37 +490,35 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         if (active) cq = reinterpret_cast<const U64u *>(sp - 4)->v;
         uint32_t k = 0;
         for (;; k += 4) {
-            if (__ballot(active) == 0) break;
+            if (__builtin_amdgcn_ballot_w64(active) == 0) break;
             if (k == chainQ) {
-                while (tail != head) fold(k);
+                while (tail) fold(k);
                 snapkey = key_seen; snap_taken = true;
-            } else if ((k & (ZGPU_M3_PERIOD - 1)) == 0 && tail != head) fold(k);
+            } else if ((k & (ZGPU_M3_PERIOD - 1)) == 0) { while (tail) fold(k); }
             uint64_t cqn = 0;
             if (active && k + 4 < avail) cqn = reinterpret_cast<const U64u *>(sp - 8 - k)->v;
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                bool pass = false;
+                // no divergent control flow in the step: idle lanes read a harmless in-range address and are masked out of the ballot
                 const uint32_t q = (uint32_t)(cq >> (48 - 16 * j)) & 0xffffu;
-                if (active) {
-                    if ((int)q < thr) active = false; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
-                    else {
-                        thr = thr_next;
-                        uint32_t b0, b1;
-                        lds_ld2bytes(boff + q, b0, b1);
-                        pass = (b0 | (b1 << 8)) == scan2;
-                    }
-                }
-                const unsigned long long m = __ballot(pass);
+                uint32_t b0, b1;
+                lds_ld2bytes(boff + q, b0, b1);
+                active = active && (int)q >= thr; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
+                if (k == 0 && j == 0) thr = thr_next;
+                const bool pass = active && (b0 | (b1 << 8)) == scan2;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                M3_STAT(0, 1); M3_STAT(1, __popcll(__builtin_amdgcn_ballot_w64(active))); M3_STAT(2, __popcll(m));
                 if (m) {
-                    if (pass) lds_st32(ring + (((tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))) & (kRing - 1)) << 2), q | lanebits | ((k + j) << 22));
-                    tail += (uint32_t)__popcll(m);
-                    if (tail - head >= 64) fold(k + j);
+                    const uint32_t rt = (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2));
+                    if (pass) lds_st32(rt + (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << 2), q | lanebits | ((k + j) << 22));
+                    tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
+                    if (tail >= 64) fold(k + j);
                 }
-                if (k + j + 1 >= avail) active = false;
+                active = active && k + j + 1 < avail;
             }
             cq = cqn;
         }
-        while (tail != head) fold(k);
+        while (tail) fold(k);
         if (!snap_taken) snapkey = key_seen;
         if (valid) {
             uint32_t full = 0, snap = 0, flags = 0;
