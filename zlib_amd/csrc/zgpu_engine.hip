@@ -23,7 +23,8 @@ bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort);
+uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
 
@@ -43,6 +44,7 @@ struct zgpu_engine {
     uint16_t *tables = nullptr;  // serial LZ only
     uint32_t tables_cap = 0;
     void *par_ws = nullptr;      // parallel LZ only
+    int exact_sort = 0;          // sticky: the fast sort's self-check failed once on this engine (zgpu_lz_sorted.hip, pass V)
     uint32_t par_cap = 0;
     uint64_t *offsets = nullptr; // nchunks+1 segment offsets of the current call
     uint64_t offsets_cap = 0;
@@ -200,6 +202,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     RunStateHost rs{}; rs.out_total = wrap ? 2 : 0; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    const bool check_sort = impl == ZGPU_LZ_SORTED && !e->exact_sort;
+    uint32_t sort_fault = 0;
+    if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
 
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
@@ -210,7 +215,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            if (impl == ZGPU_LZ_SORTED) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
+            if (impl == ZGPU_LZ_SORTED) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort);
             else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {
@@ -227,8 +232,13 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         ZGPU_HIP_CHECK(hipGetLastError());
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
+    if (check_sort) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault, lz_sorted_fault_word(e->par_ws), 4, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     collect_spans(e);
+    if (sort_fault) { // the LDS did not serve an atomic's lanes in lane order: redo the call with the sort that does not rely on it
+        e->exact_sort = 1;
+        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st);
+    }
     if (rs.overflow || (wrap && out_cap < rs.out_total + 4)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
     if (wrap) {

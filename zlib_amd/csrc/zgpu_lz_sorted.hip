@@ -27,12 +27,23 @@ void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
 
+__device__ inline uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+// wave-private LDS words by byte offset (plain C++ volatile accesses through a generic pointer compile to flat_* memory instructions)
+__device__ inline void lds_st32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline void lds_st16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline void lds_max32(uint32_t a, uint32_t v) { asm volatile("ds_max_u32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline uint32_t lds_ld32(uint32_t a) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ inline uint32_t lds_ld16(uint32_t a) { uint32_t v; asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+
+__device__ inline void lds_st8(uint32_t a, uint32_t v) { asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ inline uint32_t lds_ld8(uint32_t a) { uint32_t v; asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
+
 constexpr uint32_t kSuperS = 1024;   // positions per superblock of the sort passes
-constexpr uint32_t kSPad = 8;        // u16 entries in front of every chunk's S (group loads may reach below index 0)
+constexpr uint32_t kSPad = 8;        // entries in front of every chunk's S (group loads may reach below index 0)
 constexpr uint32_t kSStride = kChunkMax + kSPad;
 
-// per-chunk workspace layout (bytes): S | rank | idx | records
-size_t lz_sorted_workspace_bytes(uint32_t batch) { return (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kChunkMax * 2 + kChunkMax * 8) + 1024; }
+// workspace layout: 256-byte header (fault word) | S (u16) | rank, then idx, by position (u16) | bucket-head bits | records
+size_t lz_sorted_workspace_bytes(uint32_t batch) { return 256 + (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kChunkMax / 8 + kChunkMax * 8) + 1024; }
 
 // ------------------------------------------------------------------------------------------------- K1'
 // One 256-lane workgroup (4 waves) per chunk.  Pass A is sequential in position order only among positions that share a
@@ -44,7 +55,7 @@ size_t lz_sorted_workspace_bytes(uint32_t batch) { return (size_t)batch * (kSStr
 #endif
 constexpr uint32_t kSortWaves = ZGPU_SORT_WAVES, kSortThreads = 64 * kSortWaves; // waves per chunk: 4 or 8 (or 16)
 
-__global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint16_t *__restrict__ idx_all)
+__global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all)
 {
     __shared__ uint16_t cnt[kHashSize];                                         // counts, then bucket starts
     __shared__ __attribute__((aligned(16))) uint32_t in_stage[kSuperS / 4 + 4]; // 1 KiB of input + 8 bytes of the next
@@ -55,7 +66,9 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
-    uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax, *ix = idx_all + (size_t)c * kChunkMax;
+    uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
+    uint32_t *hd = heads_all + (size_t)c * (kChunkMax / 32);
+    for (uint32_t i = tid; i < kChunkMax / 32; i += kSortThreads) hd[i] = 0; // (pass C sets bits; the barriers of pass A lie in between)
     for (uint32_t i = tid; i < kHashSize / 2; i += kSortThreads) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
     volatile uint16_t *vcnt = cnt;
@@ -153,15 +166,183 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
             if (p < npos) {
                 const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]), r = rk[p], id = (uint32_t)cnt[h] + r;
                 S[id] = (uint16_t)p;
-                ix[id] = (uint16_t)r; // rank in S order: the match kernel walks S, not the positions
+                if (r == 0) atomicOr(&hd[id >> 5], 1u << (id & 31u)); // bucket head
             }
         }
         __syncthreads();
     }
 }
 
+// ------------------------------------------------------------------------------------------------- K1''
+// The default sort.  What makes a counting sort that keeps equal keys in position order sequential is the ranking,
+// rank(p) = count[h(p)]++ taken in position order.  On this hardware one LDS atomic instruction serves the lanes that
+// hit the same address in ascending lane order (scripts/micro/lds_atomic_order.hip: no exception in 5e10 lane-operations),
+// and the LDS serves the instructions of a CU in arrival order.  So 64 positions are ranked by ONE ds_add_rtn_u32 (two
+// 16-bit counts per word; the add is 1 or 1<<16), and all that has to be sequenced is the order in which the 16 waves of
+// the workgroup issue their instructions: a token in LDS walks round the waves, a turn is 8 instructions (512 positions)
+// followed by the token store -- same wave, same queue, so the next holder's atomics arrive behind them.  Hashes are
+// computed, and ranks stored, outside the turn.
+// The lane order inside an atomic is an observed property, not an architected one: pass V checks the result (a bucket
+// must ascend), and a violation makes the engine redo the call with sort_kernel above, which relies on ballots only.
+// Output: S (positions, u16) and one bit per S index that marks the first entry of a bucket -- the rank of an entry in its
+// bucket, which bounds its chain, is its distance from the last marked index.
+#ifdef ZGPU_S3_STOP // timing builds only (scripts/sweep_variants.sh): leave after phase N with a trivially valid S (no candidates anywhere)
+#define S3_STOP(N) do { if (ZGPU_S3_STOP == N) { for (uint32_t i_ = tid; i_ < kChunkMax; i_ += kS3Threads) { S[i_] = (uint16_t)i_; if (i_ < kChunkMax / 32) hd[i_] = ~0u; } return; } } while (0)
+#else
+#define S3_STOP(N) do { } while (0)
+#endif
+constexpr uint32_t kS3Threads = 1024, kS3Waves = kS3Threads / 64, kS3TurnSteps = 8, kS3TurnPos = 64 * kS3TurnSteps, kS3Batch = 8;
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+__device__ inline uint32_t lds_add_rtn32_nowait(uint32_t a, uint32_t v) { uint32_t o; asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(v) : "memory"); return o; }
+
+__global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all,
+                                                           uint32_t *__restrict__ fault)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[kHashSize / 2]; // count of hash h in half (h & 1) of word h >> 1; later the bucket starts
+    __shared__ uint32_t wave_tot[kS3Waves];
+    __shared__ uint32_t token;
+    __shared__ uint32_t heads[kChunkMax / 32]; // bit i: S[i] is the first entry of its bucket
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
+    uint32_t *hd = heads_all + (size_t)c * (kChunkMax / 32);
+    uint32_t last_of_half0 = 0;
+    const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
+    const uint32_t cnt_a = lds_off(cnt), tok_a = lds_off(&token);
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(cnt);
+        for (uint32_t i = tid; i < kHashSize * 2 / 16; i += kS3Threads) z[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) token = 0;
+        for (uint32_t i = tid; i < kChunkMax / 32; i += kS3Threads) heads[i] = 0;
+    }
+    __syncthreads();
+    S3_STOP(0);
+    auto bytes3 = [&](uint32_t p) -> uint32_t { // b0 | b1<<8 | b2<<16 of position p < npos
+        if (p + 4 <= n) return reinterpret_cast<const U32u *>(src + p)->v & 0xffffffu;
+        return (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+    };
+    auto hash_of = [](uint32_t v) { return hash3(v & 255u, (v >> 8) & 255u, v >> 16); };
+
+    // ---- pass A: rank(p) ----
+    {
+        uint32_t hv[kS3TurnSteps];
+        auto preload = [&](uint32_t T) {
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) { const uint32_t p = T * kS3TurnPos + 64 * u + lane; hv[u] = p < npos ? hash_of(bytes3(p)) : ~0u; }
+        };
+        if (wave < nturns) preload(wave);
+#pragma unroll 1
+        for (uint32_t T = wave; T < nturns; T += kS3Waves) {
+            uint32_t aa[kS3TurnSteps], vv[kS3TurnSteps], old[kS3TurnSteps]; // nothing but the atomics happens while the token is held
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                const bool ok = hv[u] != ~0u;
+                aa[u] = cnt_a + (ok ? (hv[u] >> 1) << 2 : 0);
+                vv[u] = ok ? 1u << ((hv[u] & 1u) << 4) : 0; // adding 0 is harmless
+            }
+            while (lds_ld32(tok_a) != T) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) old[u] = lds_add_rtn32_nowait(aa[u], vv[u]);
+            lds_st32(tok_a, T + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
+            static_assert(kS3TurnSteps == 8, "the wait names eight results");
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                const uint32_t p = T * kS3TurnPos + 64 * u + lane;
+                if (hv[u] != ~0u) rk[p] = (uint16_t)(old[u] >> ((hv[u] & 1u) << 4));
+            }
+            if (T + kS3Waves < nturns) preload(T + kS3Waves);
+        }
+    }
+    __syncthreads();
+    S3_STOP(1);
+
+    // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place); 32 consecutive counts per lane ----
+    {
+        constexpr uint32_t per = kHashSize / kS3Threads, nv = per * 2 / 16; // counts and 16-byte vectors per lane
+        static_assert(per % 8 == 0, "a lane scans whole 16-byte vectors");
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt) + tid * nv;
+        uint32_t v[nv * 4], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < nv; i++) { const uint4 q = c4[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+#pragma unroll
+        for (uint32_t i = 0; i < nv * 4; i++) sum += (v[i] & 0xffffu) + (v[i] >> 16);
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        uint32_t basev = x - sum;
+        for (uint32_t w = 0; w < wave; w++) basev += wave_tot[w];
+#pragma unroll
+        for (uint32_t i = 0; i < nv * 4; i++) {
+            const uint32_t c0 = v[i] & 0xffffu, c1 = v[i] >> 16;
+            v[i] = (basev & 0xffffu) | ((basev + c0) << 16);
+            basev += c0 + c1;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < nv; i++) c4[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    __syncthreads();
+    S3_STOP(2);
+
+    // ---- pass C0: idx(p) = start(hash) + rank, kept in place of the rank; a bit per bucket head ----
+    const uint16_t *start = reinterpret_cast<const uint16_t *>(cnt);
+    for (uint32_t i0 = 0; i0 < npos; i0 += kS3Threads * kS3Batch) {
+        uint32_t bv[kS3Batch], rv[kS3Batch];
+#pragma unroll
+        for (uint32_t u = 0; u < kS3Batch; u++) { const uint32_t p = i0 + u * kS3Threads + tid; bv[u] = p < npos ? bytes3(p) : 0; rv[u] = p < npos ? rk[p] : 0; }
+#pragma unroll
+        for (uint32_t u = 0; u < kS3Batch; u++) {
+            const uint32_t p = i0 + u * kS3Threads + tid;
+            if (p < npos) {
+                const uint32_t id = (uint32_t)start[hash_of(bv[u])] + rv[u];
+                rk[p] = (uint16_t)id;
+                if (rv[u] == 0) atomicOr(&heads[id >> 5], 1u << (id & 31u));
+            }
+        }
+    }
+    __syncthreads();
+    S3_STOP(3);
+    for (uint32_t i = tid; i < kChunkMax / 32; i += kS3Threads) hd[i] = heads[i];
+
+    // ---- pass C1: the scatter itself, through LDS (a scattered 2-byte store to HBM costs a whole partial line): the half of S
+    //      with idx >> 15 == half is assembled in the memory of the dead count table and written out in order ----
+    uint16_t *stage = reinterpret_cast<uint16_t *>(cnt);
+    bool bad = false;
+    for (uint32_t half = 0; half < 2 && half * 32768u < npos; half++) {
+        __syncthreads(); // the table (pass C0), or the previous half's write-out, is done with this memory
+        for (uint32_t i0 = 0; i0 < npos; i0 += kS3Threads * kS3Batch) {
+            uint32_t iv[kS3Batch];
+#pragma unroll
+            for (uint32_t u = 0; u < kS3Batch; u++) { const uint32_t p = i0 + u * kS3Threads + tid; iv[u] = p < npos ? rk[p] : ~0u; }
+#pragma unroll
+            for (uint32_t u = 0; u < kS3Batch; u++) if ((iv[u] >> 15) == half) stage[iv[u] & 32767u] = (uint16_t)(i0 + u * kS3Threads + tid);
+        }
+        __syncthreads();
+        const uint32_t cntH = npos - half * 32768u < 32768u ? npos - half * 32768u : 32768u; // entries of this half
+        for (uint32_t v = tid; v * 8 < cntH; v += kS3Threads) { // 8 entries = 16 bytes per lane and step
+            const uint4 q = reinterpret_cast<const uint4 *>(stage)[v];
+            *reinterpret_cast<uint4 *>(S + half * 32768u + v * 8) = q; // S is 16-byte aligned (kSPad); the tail past npos is don't-care
+            // pass V: inside a bucket the positions must ascend (the lane order of the LDS atomic, see above)
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const uint32_t hb = (heads[(half * 32768u + v * 8) >> 5] >> ((v * 8) & 31u)) & 0xffu;
+            uint32_t prev = v ? stage[v * 8 - 1] : (half ? last_of_half0 : 0);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t cur = (w[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                if (v * 8 + j < cntH && !((hb >> j) & 1u) && prev >= cur) bad = true;
+                prev = cur;
+            }
+        }
+        if (half == 0 && npos > 32768u) { __syncthreads(); last_of_half0 = stage[32767]; } // (uniform branch)
+    }
+    if (bad) atomicOr(fault, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------- K2'
-__device__ inline uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 __device__ inline uint32_t lds_ld32u(uint32_t a) // 4 bytes at any LDS byte offset: aligned ds_read2_b32 + v_alignbyte
 {
     uint64_t v; const uint32_t al = a & ~3u;
@@ -172,33 +353,8 @@ __device__ inline void lds_ld2bytes(uint32_t a, uint32_t &b0, uint32_t &b1)
 {
     asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(a) : "memory");
 }
-__device__ inline uint64_t gload64u(const uint16_t *p) // 8 bytes at 2-byte alignment (gfx950 serves it, scripts/micro/global_unaligned.hip)
-{
-    uint64_t v;
-    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-struct __attribute__((packed, aligned(2))) U64u { uint64_t v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950
-__device__ inline void lds_ld8bytes(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t (&b)[8])
-{
-    asm volatile("ds_read_u8 %0, %8\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %9\n\tds_read_u8 %3, %9 offset:1\n\t"
-                 "ds_read_u8 %4, %10\n\tds_read_u8 %5, %10 offset:1\n\tds_read_u8 %6, %11\n\tds_read_u8 %7, %11 offset:1\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
-}
-
-enum : uint32_t { sIdle = 0, sWalk = 1, sCmp = 2, sDone = 3 };
+struct __attribute__((packed, aligned(2))) U64u { uint64_t v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950 (scripts/micro/global_unaligned.hip)
 constexpr uint32_t kM2Threads = 1024;
-#ifndef ZGPU_M2_REFILL
-#define ZGPU_M2_REFILL 16
-#endif
-#ifndef ZGPU_M2_CMP
-#define ZGPU_M2_CMP 16
-#endif
-#ifndef ZGPU_M2_ROUNDS
-#define ZGPU_M2_ROUNDS 1
-#endif
 
 // chunk bytes -> LDS (zero padded to kChunkMax + 64), by all kM2Threads lanes of the workgroup
 __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32, uint32_t tid)
@@ -222,142 +378,6 @@ __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32
             uint32_t v = 0;
             for (uint32_t k = 0; k < 4; k++) { uint32_t a = (i << 2) + k; if (a < n) v |= (uint32_t)src[a] << (8 * (k & 3)); }
             d32[i] = v;
-        }
-    }
-}
-
-__global__ void __launch_bounds__(kM2Threads, 8) match2_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ rank_all,
-                                                               const uint16_t *__restrict__ idx_all, uint2 *__restrict__ recs)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *d32 = lds;                                  // 65536 + 64 bytes of chunk data
-    uint32_t *work_next = lds + (kChunkMax + 64) / 4;     // next unassigned position of the chunk
-    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
-    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    uint64_t lo; uint32_t n;
-    chunk_span(g, c, lo, n);
-    const uint8_t *src = g.in + lo;
-    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
-    (void)rank_all;
-    uint2 *rec = recs + (size_t)c * kChunkMax;
-    const uint32_t npos = n >= 3 ? n - 2 : 0;
-    const uint32_t base = chunk_base(g, c);
-
-    stage_chunk(src, n, d32, tid);
-    if (tid == 0) *work_next = 0;
-    for (uint32_t q2 = npos + tid; q2 < n; q2 += kM2Threads) rec[q2] = make_uint2((uint32_t)src[q2] << 24, 0); // the last two positions carry no hash
-    __syncthreads();
-
-    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32);
-    // per-lane walk state
-    uint32_t mode = sIdle, p = 0, k = 0, avail = 0, best = 0, bestq = 0, snap_best = 0, snap_q = 0, l = 0, cap = 0, nice = 0, flags = 0, scan2 = 0, q = 0;
-    int thr = 0;          // a candidate q is usable iff (int)q >= thr; thr rises by one after the first candidate (deflate.c:1588-1589 vs 1163)
-    int thr_next = 0;
-    uint64_t cq = 0;      // up to four candidates, next one in the top 16 bits
-    const uint16_t *sp = S; // &S[idx]: candidate k is sp[-1-k]
-    uint32_t sup_next = 0, sup_end = 0;
-    bool dry = false;
-
-    for (;;) {
-        const uint32_t nw = (uint32_t)__popcll(__ballot(mode == sWalk)), nc = (uint32_t)__popcll(__ballot(mode == sCmp)), nfree = 64 - nw - nc;
-
-        // ---- REFILL ----
-        if (nfree >= ZGPU_M2_REFILL || nw + nc == 0) {
-            if (mode == sDone) {
-                uint32_t full = best | ((p - bestq) << 9), snap = snap_best | ((p - snap_q) << 9);
-                if (best < kMinMatch) full = 0;
-                // the one position whose first candidate can sit at window index 32768 (NIL after the slide, deflate.c:1309-1312)
-                if (p + base == kWSize + kMaxDist && avail != 0 && (uint32_t)sp[-1] + base == kWSize) flags = 1;
-                if ((snap & 511) < kMinMatch) snap = 0;
-                rec[p] = make_uint2(full | ((uint32_t)d8[p] << 24), snap | (flags << 24));
-                mode = sIdle;
-            }
-            for (int round = 0; round < 4; round++) {
-                const unsigned long long idle = __ballot(mode == sIdle);
-                const uint32_t nidle = (uint32_t)__popcll(idle);
-                if (nidle == 0) break;
-                if (sup_next == sup_end && !dry) {
-                    uint32_t got = 0;
-                    if (lane == 0) got = atomicAdd(work_next, 256u);
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got >= npos) dry = true;
-                    else { sup_next = got; sup_end = got + 256 < npos ? got + 256 : npos; }
-                }
-                if (sup_next == sup_end) break;
-                if (mode == sIdle) {
-                    // work items are indices into S: neighbouring lanes get neighbouring entries of one hash bucket, i.e. chains
-                    // of almost equal length (lane balance) that overlap in memory (the 8-byte candidate loads hit in cache)
-                    const uint32_t wi = sup_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1));
-                    if (wi < sup_end) {
-                        const uint32_t np = S[wi];
-                        p = np;
-                        const uint32_t look = n - np;
-                        cap = look < kMaxMatch ? look : kMaxMatch;
-                        nice = cfg.nice < look ? cfg.nice : look;
-                        const int w = (int)(np + base);
-                        const int t_first = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;  // first candidate: dist <= MAX_DIST, not NIL
-                        const int t_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
-                        thr = t_first; thr_next = t_next;
-                        const uint32_t rank = rkS[wi];
-                        avail = rank < chainF ? rank : chainF;
-                        k = 0; best = kMinMatch - 1; bestq = np; snap_best = 0; snap_q = np; flags = 0;
-                        scan2 = (uint32_t)d8[np + 1] | ((uint32_t)d8[np + 2] << 8);
-                        if (avail) { sp = S + wi; mode = sWalk; }
-                        else rec[np] = make_uint2((uint32_t)d8[np] << 24, 0); // no candidate at all
-                    }
-                }
-                const uint32_t take = nidle < sup_end - sup_next ? nidle : sup_end - sup_next;
-                sup_next += take;
-            }
-            if (__ballot(mode == sWalk || mode == sCmp) == 0) {
-                if (dry && sup_next == sup_end) break;
-                continue;
-            }
-        }
-
-        // ---- COMPARE ----
-        if (nc >= ZGPU_M2_CMP || (nc > 0 && nw < 16)) {
-            while (__ballot(mode == sCmp)) {
-                if (mode == sCmp) {
-                    const uint32_t x = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + p + l);
-                    if (x == 0 && l + 4 < cap) l += 4;
-                    else {
-                        uint32_t len = x ? l + ((uint32_t)__builtin_ctz(x) >> 3) : l + 4;
-                        len = len < cap ? len : cap;
-                        if (len > best) {
-                            best = len; bestq = q; scan2 = (uint32_t)d8[p + len - 1] | ((uint32_t)d8[p + len] << 8);
-                            if (k < chainQ) { snap_best = len; snap_q = q; } // candidate number k+1 is within the quarter budget
-                        }
-                        k++;
-                        mode = (best >= nice || k >= avail) ? sDone : sWalk;
-                    }
-                }
-            }
-        }
-
-        // ---- WALK: rounds of up to four candidates (one 8-byte load of S per group of four) ----
-#pragma unroll 1
-        for (int rnd = 0; rnd < ZGPU_M2_ROUNDS; rnd++) {
-        if (mode == sWalk && (k & 3) == 0) cq = gload64u(sp - 4 - k);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (mode == sWalk) {
-                q = (uint32_t)(cq >> 48);
-                if ((int)q < thr) mode = sDone; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
-                else {
-                    thr = thr_next;
-                    uint32_t b0, b1;
-                    lds_ld2bytes(dbase + q + best - 1, b0, b1);
-                    cq <<= 16;
-                    if ((b0 | (b1 << 8)) == scan2) { mode = sCmp; l = 0; } // candidate may be longer than best: compare in full
-                    else {
-                        k++;
-                        if (k >= avail) mode = sDone;
-                        else if ((k & 3) == 0) break; // the next group of candidates is fetched at the top of the next round
-                    }
-                }
-            }
-        }
         }
     }
 }
@@ -400,14 +420,7 @@ constexpr uint32_t kM3WaveLds = kRing * 4 + 64 * 4 + 64 * 2;     // ring + slots
 constexpr uint32_t kM3DataLds = kChunkMax + 64 + 320;            // chunk bytes + zero pad + slack for reads past a garbage candidate
 constexpr uint32_t kM3Lds = kM3DataLds + 16 + (kM2Threads / 64) * kM3WaveLds;
 
-// wave-private LDS words by byte offset (plain C++ volatile accesses through a generic pointer compile to flat_* memory instructions)
-__device__ inline void lds_st32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
-__device__ inline void lds_st16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
-__device__ inline void lds_max32(uint32_t a, uint32_t v) { asm volatile("ds_max_u32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
-__device__ inline uint32_t lds_ld32(uint32_t a) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
-__device__ inline uint32_t lds_ld16(uint32_t a) { uint32_t v; asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v; }
-
-__global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint16_t *__restrict__ idx_all,
+__global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ heads_all,
                                                                uint2 *__restrict__ recs)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -419,7 +432,8 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
-    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rkS = idx_all + (size_t)c * kChunkMax; // rank of S[i], in S order
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
+    const unsigned long long *hd = reinterpret_cast<const unsigned long long *>(heads_all + (size_t)c * (kChunkMax / 32)); // bit i: S[i] starts a bucket
     uint2 *rec = recs + (size_t)c * kChunkMax;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
     const uint32_t base = chunk_base(g, c);
@@ -437,7 +451,19 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         const uint32_t wi = (blk << 6) + lane;
         const bool valid = wi < npos;
         uint32_t p = 0, avail = 0;
-        if (valid) { p = S[wi]; const uint32_t rank = rkS[wi]; avail = rank < chainF ? rank : chainF; }
+        if (valid) p = S[wi];
+        {   // rank of an entry in its bucket = distance from the last bucket head at or below it; only min(rank, chain) matters.
+            // The block is word `blk` of the head bits; heads below it are the same for all lanes (wave-uniform search).
+            const unsigned long long m = hd[blk];
+            uint32_t below = ~0u; // distance from index 64*blk to the last head below the block, if within the chain budget
+            for (uint32_t w2 = blk, d = 0; w2 > 0 && d < chainF; d += 64) {
+                const unsigned long long x = hd[--w2];
+                if (x) { below = d + (uint32_t)__builtin_clzll(x) + 1; break; }
+            }
+            const unsigned long long mine = m & ((2ull << lane) - 1);
+            uint32_t rank = mine ? (uint32_t)__builtin_clzll(mine) - (63 - lane) : below == ~0u ? chainF : lane + below;
+            if (valid) avail = rank < chainF ? rank : chainF;
+        }
         const int w = (int)(p + base);
         int thr = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;                 // first candidate: dist <= MAX_DIST, not NIL
         const int thr_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
@@ -486,7 +512,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
             }
         };
 
-        uint64_t cq = 0;
+        uint64_t cq = 0; // four candidates, the nearest in the top 16 bits
         if (active) cq = reinterpret_cast<const U64u *>(sp - 4)->v;
         uint32_t k = 0;
         for (;; k += 4) {
@@ -538,31 +564,39 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     }
 }
 
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)
+// `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort)
 {
     uint8_t *w = static_cast<uint8_t *>(workspace);
     const size_t nch = g.nchunks;
-    uint16_t *S = reinterpret_cast<uint16_t *>(w);
-    uint16_t *rk = reinterpret_cast<uint16_t *>(w + ((nch * kSStride * 2 + 255) & ~(size_t)255));
-    uint16_t *ix = rk + nch * kChunkMax;
-    uint2 *recs = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(ix + nch * kChunkMax));
+    uint32_t *fault = reinterpret_cast<uint32_t *>(w);
+    uint16_t *S = reinterpret_cast<uint16_t *>(w + 256);
+    uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
+    uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
+    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * (kChunkMax / 32));
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
-    hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, ix);
+    static int sort_env = -1;
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (exact_sort || sort_env == 1) hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads);
+    else {
+        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault);
+        static int fault_test = -1; // tests/test_gpu_deflate.py: exercise the engine's fallback without a real fault
+        if (fault_test < 0) fault_test = getenv("ZGPU_SORT_FAULT_TEST") ? 1 : 0;
+        if (fault_test) hipMemsetAsync(fault, 1, 4, st);
+    }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
-    const size_t lds_bytes = (kChunkMax + 64) + 64 + 320; // slack: speculative quick-reject reads may reach 258 bytes past a garbage candidate
-    static bool opt_in = false, opt_in3 = false;
-    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(match2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); opt_in = true; }
-    static int impl = -1;
-    if (impl < 0) { const char *e = getenv("ZGPU_MATCH"); impl = e ? atoi(e) : 3; }
+    static bool opt_in3 = false;
     if (!opt_in3) { hipFuncSetAttribute(reinterpret_cast<const void *>(match3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kM3Lds); opt_in3 = true; }
-    if (impl == 2) hipLaunchKernelGGL(match2_kernel, dim3(g.nchunks), dim3(kM2Threads), lds_bytes, st, g, cfg, S, rk, ix, recs);
-    else hipLaunchKernelGGL(match3_kernel, dim3(g.nchunks), dim3(kM2Threads), kM3Lds, st, g, cfg, S, ix, recs);
+    hipLaunchKernelGGL(match3_kernel, dim3(g.nchunks), dim3(kM2Threads), kM3Lds, st, g, cfg, S, heads, recs);
     prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
     prof_span_begin(prof, st, &ev);
     launch_parse(g, cfg, recs, tokens, meta, st);
     prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
 }
+
+// the word sort3's pass V raises (first word of the workspace)
+uint32_t *lz_sorted_fault_word(void *workspace) { return static_cast<uint32_t *>(workspace); }
 
 } // namespace zgpu
