@@ -43,7 +43,38 @@ constexpr uint32_t kSPad = 8;        // entries in front of every chunk's S (gro
 constexpr uint32_t kSStride = kChunkMax + kSPad;
 
 // workspace layout: 256-byte header (fault word) | S (u16) | rank, then idx, by position (u16) | bucket-head bits | records
-size_t lz_sorted_workspace_bytes(uint32_t batch) { return 256 + (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kChunkMax / 8 + kChunkMax * 8) + 1024; }
+
+constexpr uint32_t kHeadWords = kChunkMax / 32;                  // dwords of bucket-head bits per chunk ...
+constexpr uint32_t kHeadStride = kHeadWords + kChunkMax / 64 / 2; // ... followed by one u16 per 64 S indices (dwords per chunk)
+
+size_t lz_sorted_workspace_bytes(uint32_t batch) { return 256 + (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kHeadStride * 4 + kChunkMax * 8) + 1024; }
+
+// For block w of 64 S indices (1024 lanes, lane w holds the 64 head bits of its block): the distance from index 64*w down
+// to the last bucket head below the block, 65535 if there is none (w == 0) or it is farther.  The rank of an S entry in
+// its bucket is its distance from the last head at or below it, and this is the part of it that lies outside its own block.
+__device__ inline uint32_t heads_below(unsigned long long x, uint32_t tid, uint32_t *wave_scratch)
+{
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t v = x ? 64u * tid + 64u - (uint32_t)__builtin_clzll(x) : 0; // 1 + index of the highest head of the block, 0: none
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if ((int)lane >= d && y > inc) inc = y; }
+    if (lane == 63) wave_scratch[wave] = inc;
+    __syncthreads();
+    uint32_t ex = __shfl_up(inc, 1);
+    if (lane == 0) ex = 0;
+    for (uint32_t w = 0; w < wave; w++) { const uint32_t y = wave_scratch[w]; if (y > ex) ex = y; }
+    const uint32_t dist = 64u * tid - (ex - 1);
+    return ex && dist < 65535u ? dist : 65535u;
+}
+
+__global__ void __launch_bounds__(1024) heads_below_kernel(uint32_t *__restrict__ heads_all) // after sort_kernel (the fallback path)
+{
+    __shared__ uint32_t scratch[16];
+    uint32_t *hd = heads_all + (size_t)blockIdx.x * kHeadStride;
+    const uint32_t b = heads_below(reinterpret_cast<const unsigned long long *>(hd)[threadIdx.x], threadIdx.x, scratch);
+    reinterpret_cast<uint16_t *>(hd + kHeadWords)[threadIdx.x] = (uint16_t)b;
+}
 
 // ------------------------------------------------------------------------------------------------- K1'
 // One 256-lane workgroup (4 waves) per chunk.  Pass A is sequential in position order only among positions that share a
@@ -67,7 +98,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
-    uint32_t *hd = heads_all + (size_t)c * (kChunkMax / 32);
+    uint32_t *hd = heads_all + (size_t)c * kHeadStride;
     for (uint32_t i = tid; i < kChunkMax / 32; i += kSortThreads) hd[i] = 0; // (pass C sets bits; the barriers of pass A lie in between)
     for (uint32_t i = tid; i < kHashSize / 2; i += kSortThreads) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
@@ -187,7 +218,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
 // Output: S (positions, u16) and one bit per S index that marks the first entry of a bucket -- the rank of an entry in its
 // bucket, which bounds its chain, is its distance from the last marked index.
 #ifdef ZGPU_S3_STOP // timing builds only (scripts/sweep_variants.sh): leave after phase N with a trivially valid S (no candidates anywhere)
-#define S3_STOP(N) do { if (ZGPU_S3_STOP == N) { for (uint32_t i_ = tid; i_ < kChunkMax; i_ += kS3Threads) { S[i_] = (uint16_t)i_; if (i_ < kChunkMax / 32) hd[i_] = ~0u; } return; } } while (0)
+#define S3_STOP(N) do { if (ZGPU_S3_STOP == N) { for (uint32_t i_ = tid; i_ < kChunkMax; i_ += kS3Threads) { S[i_] = (uint16_t)i_; if (i_ < kHeadStride) hd[i_] = ~0u; } return; } } while (0)
 #else
 #define S3_STOP(N) do { } while (0)
 #endif
@@ -201,13 +232,13 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kHashSize / 2]; // count of hash h in half (h & 1) of word h >> 1; later the bucket starts
     __shared__ uint32_t wave_tot[kS3Waves];
     __shared__ uint32_t token;
-    __shared__ uint32_t heads[kChunkMax / 32]; // bit i: S[i] is the first entry of its bucket
+    __shared__ __attribute__((aligned(8))) uint32_t heads[kChunkMax / 32]; // bit i: S[i] is the first entry of its bucket
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
-    uint32_t *hd = heads_all + (size_t)c * (kChunkMax / 32);
+    uint32_t *hd = heads_all + (size_t)c * kHeadStride;
     uint32_t last_of_half0 = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
     const uint32_t cnt_a = lds_off(cnt), tok_a = lds_off(&token);
@@ -307,6 +338,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     __syncthreads();
     S3_STOP(3);
     for (uint32_t i = tid; i < kChunkMax / 32; i += kS3Threads) hd[i] = heads[i];
+    reinterpret_cast<uint16_t *>(hd + kHeadWords)[tid] = (uint16_t)heads_below(reinterpret_cast<const unsigned long long *>(heads)[tid], tid, wave_tot);
 
     // ---- pass C1: the scatter itself, through LDS (a scattered 2-byte store to HBM costs a whole partial line): the half of S
     //      with idx >> 15 == half is assembled in the memory of the dead count table and written out in order ----
@@ -433,7 +465,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
-    const unsigned long long *hd = reinterpret_cast<const unsigned long long *>(heads_all + (size_t)c * (kChunkMax / 32)); // bit i: S[i] starts a bucket
+    const unsigned long long *hd = reinterpret_cast<const unsigned long long *>(heads_all + (size_t)c * kHeadStride); // bit i: S[i] starts a bucket
     uint2 *rec = recs + (size_t)c * kChunkMax;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
     const uint32_t base = chunk_base(g, c);
@@ -443,25 +475,23 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     __syncthreads();
 
     const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = (npos + 63) >> 6;
-    for (;;) {
-        uint32_t blk = 0;
-        if (lane == 0) blk = atomicAdd(work_next, 1u);
-        blk = __builtin_amdgcn_readfirstlane(blk);
-        if (blk >= nblk) break;
+    const uint16_t *hb = reinterpret_cast<const uint16_t *>(heads_all + (size_t)c * kHeadStride + kHeadWords); // heads_below per block
+    auto grab = [&]() { uint32_t b = 0; if (lane == 0) b = atomicAdd(work_next, 1u); return (uint32_t)__builtin_amdgcn_readfirstlane(b); };
+    // the next block's entry, head bits and heads_below are fetched while the current block is searched
+    uint32_t blk = grab(), p_nx = 0, below_nx = 0;
+    unsigned long long m_nx = 0;
+    if (blk < nblk) { const uint32_t wi = (blk << 6) + lane; p_nx = wi < npos ? S[wi] : 0; m_nx = hd[blk]; below_nx = hb[blk]; }
+    while (blk < nblk) {
         const uint32_t wi = (blk << 6) + lane;
         const bool valid = wi < npos;
-        uint32_t p = 0, avail = 0;
-        if (valid) p = S[wi];
-        {   // rank of an entry in its bucket = distance from the last bucket head at or below it; only min(rank, chain) matters.
-            // The block is word `blk` of the head bits; heads below it are the same for all lanes (wave-uniform search).
-            const unsigned long long m = hd[blk];
-            uint32_t below = ~0u; // distance from index 64*blk to the last head below the block, if within the chain budget
-            for (uint32_t w2 = blk, d = 0; w2 > 0 && d < chainF; d += 64) {
-                const unsigned long long x = hd[--w2];
-                if (x) { below = d + (uint32_t)__builtin_clzll(x) + 1; break; }
-            }
+        const uint32_t p = p_nx, below = below_nx;
+        const unsigned long long m = m_nx;
+        const uint32_t blk_nx = grab();
+        if (blk_nx < nblk) { const uint32_t wn = (blk_nx << 6) + lane; p_nx = wn < npos ? S[wn] : 0; m_nx = hd[blk_nx]; below_nx = hb[blk_nx]; }
+        uint32_t avail = 0;
+        {   // rank of an entry in its bucket = distance from the last bucket head at or below it; only min(rank, chain) matters
             const unsigned long long mine = m & ((2ull << lane) - 1);
-            uint32_t rank = mine ? (uint32_t)__builtin_clzll(mine) - (63 - lane) : below == ~0u ? chainF : lane + below;
+            const uint32_t rank = mine ? (uint32_t)__builtin_clzll(mine) - (63 - lane) : lane + below;
             if (valid) avail = rank < chainF ? rank : chainF;
         }
         const int w = (int)(p + base);
@@ -561,6 +591,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
             if (p + base == kWSize + kMaxDist && avail != 0 && (uint32_t)sp[-1] + base == kWSize) flags = 1;
             rec[p] = make_uint2(full | ((uint32_t)d8[p] << 24), snap | (flags << 24));
         }
+        blk = blk_nx;
     }
 }
 
@@ -573,12 +604,15 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     uint16_t *S = reinterpret_cast<uint16_t *>(w + 256);
     uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
     uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
-    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * (kChunkMax / 32));
+    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * kHeadStride);
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
     static int sort_env = -1;
     if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
-    if (exact_sort || sort_env == 1) hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads);
+    if (exact_sort || sort_env == 1) {
+        hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads);
+        hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
+    }
     else {
         hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault);
         static int fault_test = -1; // tests/test_gpu_deflate.py: exercise the engine's fallback without a real fault
