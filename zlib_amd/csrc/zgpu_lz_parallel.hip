@@ -22,6 +22,7 @@
 // reference turns into NIL when it slides the window (deflate.c:1309-1312); K3 applies it only once the slide has
 // happened.
 #include "zgpu_common.h"
+#include <cstdlib>
 #include "../../include/zamd_gpu.h"
 
 namespace zgpu {
@@ -440,9 +441,14 @@ __global__ void __launch_bounds__(64) parse_kernel(ChunkGeom g, LevelCfg cfg, co
     meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
 }
 
+void launch_parse2(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st); // zgpu_lz_parse.hip
+
 void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
 {
-    hipLaunchKernelGGL(parse_kernel, dim3((g.nchunks + 63) / 64), dim3(64), 0, st, g, cfg, recs, tokens, meta);
+    static int serial = -1; // ZGPU_PARSE=1: the lane-per-chunk restatement of the reference loop (kept as the cross-check)
+    if (serial < 0) { const char *e = getenv("ZGPU_PARSE"); serial = e && atoi(e) == 1 ? 1 : 0; }
+    if (serial) hipLaunchKernelGGL(parse_kernel, dim3((g.nchunks + 63) / 64), dim3(64), 0, st, g, cfg, recs, tokens, meta);
+    else launch_parse2(g, cfg, recs, tokens, meta, st);
 }
 
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)

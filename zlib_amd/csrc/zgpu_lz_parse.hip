@@ -1,0 +1,272 @@
+// zgpu_lz_parse.hip -- K3, parallel form: the deflate_slow control flow (/root/reference/qcsrc/deflate.c:1554-1674) over the
+// match records of a chunk, one 1024-lane workgroup per chunk, no serial walk over the positions.
+//
+// parse_kernel (zgpu_lz_parallel.hip) runs the reference's loop as it stands, one lane per chunk: ~25 000 dependent
+// record loads per chunk, 42 ms however many chunks are in flight.  The loop has more structure than that:
+//
+//   * After every emitted match the state is the start state (no literal pending, prev_length = MIN_MATCH-1) at the
+//     position behind the match.  Call such a position a Q0 position.
+//   * From a Q0 position q the loop emits literals up to the first position r >= q whose record holds a match
+//     (has(r): length >= 3 after the TOO_FAR rule, deflate.c:1597-1606), then plays the lazy-evaluation game from r: while the
+//     record of the next position is longer than the match in hand, the byte is emitted as a literal and the longer match
+//     taken (deflate.c:1611-1648).  The game depends on r alone -- not on how r was reached -- so E(r), the Q0 position it
+//     ends in, and the match (start m, length, distance) it emits are functions of r.
+//   * The window slide (`off`, deflate.c:1293) fires at the first VISITED position at or above a threshold that depends
+//     on n and the chunk base only, so "has the slide happened" is a function of the position as well.
+//
+// So the has-positions form a forest, r -> nextHas(E(r)), and the parse is the path from nextHas(0).  The kernel
+//   1. marks has(p) for all p (bitmap),
+//   2. per window of 16384 positions: computes the successor of every has-position in the window (lanes = positions),
+//      marks the path by pointer doubling (mark what the marked reach in 2^k hops, then square the table; 14 rounds), and
+//      hands the path's exit to the next window,
+//   3. for every marked r replays the game: one match token at m, positions (m, m+len) covered,
+//   4. every position not covered is a token (a literal, or the match at m): token index = prefix count of such positions,
+//   5. writes the tokens, and derives the 16383-token block cuts and the "may not be stored" flags (trees.c:921-1016 via
+//      deflate.c FLUSH_BLOCK_ONLY) from token indices.
+// Output is identical to parse_kernel's: tokens, ntok, nostore, in_bytes.
+#include "zgpu_common.h"
+
+namespace zgpu {
+
+constexpr uint32_t kP2Threads = 1024, kP2Win = 16384, kP2Own = kP2Win / kP2Threads, kP2Rounds = 14;
+constexpr uint32_t kP2Words = kChunkMax / 32;
+constexpr uint32_t kNone = 0xffffffffu;
+static_assert((1u << kP2Rounds) >= kP2Win, "doubling must cover a window");
+
+struct ParseCtx {
+    const uint2 *rec;
+    uint32_t n, base, good, lazy;
+    int slide_at; // visited positions >= slide_at see the slid window (off != 0)
+    __device__ bool slid(uint32_t p) const { return (int)p >= slide_at; }
+    // the match the loop takes at p when the match in hand has length prev_len (deflate.c:1585-1606); 2 = none
+    __device__ uint32_t take(uint32_t p, uint32_t prev_len, uint2 r, uint32_t &dist) const
+    {
+        if (prev_len >= lazy) return kMinMatch - 1;
+        const uint32_t pick = prev_len >= good ? r.y : r.x;
+        uint32_t len = pick & 511u;
+        const uint32_t d = (pick >> 9) & 32767u;
+        if (((r.y >> 24) & 1u) && slid(p)) len = 0; // first candidate became NIL in the slide
+        if (len <= prev_len) return kMinMatch - 1;
+        if (len == kMinMatch && d > kTooFar) return kMinMatch - 1;
+        dist = d;
+        return len;
+    }
+    // the lazy-evaluation game from a has-position r: match start m, length, distance
+    __device__ void game(uint32_t r, uint2 rr, uint32_t &m, uint32_t &len, uint32_t &dist) const
+    {
+        uint32_t L, D = 0;
+        L = take(r, kMinMatch - 1, rr, D);
+        uint32_t q = r + 1;
+        for (;;) { // a match of L >= 3 bytes at q-1 ends inside the chunk, so q <= n-2 has a record
+            uint32_t D2 = 0;
+            const uint32_t L2 = take(q, L, rec[q], D2);
+            if (L2 <= L) break; // (take returns 2 when it keeps the match in hand)
+            L = L2; D = D2; q++;
+        }
+        m = q - 1; len = L; dist = D;
+    }
+};
+
+__device__ inline uint32_t next_bit(const uint32_t *bits, uint32_t x, uint32_t nwords) // smallest set bit index >= x, or kNone
+{
+    uint32_t w = x >> 5;
+    if (w >= nwords) return kNone;
+    uint32_t v = bits[w] & (~0u << (x & 31u));
+    while (v == 0) { if (++w >= nwords) return kNone; v = bits[w]; }
+    return (w << 5) + (uint32_t)__builtin_ctz(v);
+}
+
+__global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
+                                                            ChunkMeta *meta)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t J[kP2Win]; // successor of a has-position, window-relative; later COV | MAT | word bases
+    __shared__ uint32_t HAS[kP2Words], MARK[kP2Words];
+    __shared__ uint32_t wave_tot[kP2Threads / 64];
+    __shared__ uint32_t sh_entry, sh_last;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    ParseCtx cx;
+    cx.rec = recs + (size_t)c * kChunkMax;
+    cx.n = n; cx.base = chunk_base(g, c); cx.good = cfg.good; cx.lazy = cfg.lazy;
+    {
+        // deflate.c:1278-1310 as a function of the position: the first check of "lookahead < MIN_LOOKAHEAD" happens at the first
+        // visited p > buffered0 - 262, later ones at p > n - 262; the slide needs p + base >= WSIZE + MAX_DIST on top
+        const int room = (int)(2 * kWSize - cx.base), b0 = (int)n < room ? (int)n : room;
+        const int a = b0 - (int)kMinLookahead + 1, b = (int)(kWSize + kMaxDist) - (int)cx.base;
+        cx.slide_at = a > b ? a : b;
+    }
+    uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t nwords = (n + 31) >> 5;
+
+    // ---- 1. has(p) ----
+    for (uint32_t i = tid; i < kP2Words; i += kP2Threads) MARK[i] = 0;
+    for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads) {
+        const uint32_t p = p0 + tid;
+        bool h = false;
+        if (p < n) { uint32_t d; h = cx.take(p, kMinMatch - 1, cx.rec[p], d) >= kMinMatch; }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(h);
+        if (lane == 0) { HAS[(p0 >> 5) + 2 * wave] = (uint32_t)b; HAS[(p0 >> 5) + 2 * wave + 1] = (uint32_t)(b >> 32); }
+    }
+    __syncthreads();
+
+    // ---- 2. the path, window by window ----
+    if (tid == 0) sh_entry = next_bit(HAS, 0, nwords);
+    __syncthreads();
+    for (uint32_t w0 = 0; w0 < n; w0 += kP2Win) {
+        const uint32_t wend = w0 + kP2Win;
+        uint32_t entry = sh_entry;
+        if (entry == kNone) break;       // (uniform) no match from here to the end
+        if (entry >= wend) continue;     // (uniform) the path jumps over this window
+        // 2a. successors
+#pragma unroll 4
+        for (uint32_t i = 0; i < kP2Own; i++) {
+            const uint32_t x = i * kP2Threads + tid, p = w0 + x;
+            uint32_t succ = 0xffffu;
+            if (p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u)) {
+                uint32_t m, L, D;
+                cx.game(p, cx.rec[p], m, L, D);
+                const uint32_t t = next_bit(HAS, m + L, nwords);
+                if (t < wend) succ = t - w0;
+            }
+            J[x] = (uint16_t)succ;
+        }
+        if (tid == 0) atomicOr(&MARK[entry >> 5], 1u << (entry & 31u));
+        __syncthreads();
+        // 2b. doubling: after round k the marked set is the first 2^(k+1) path nodes of the window
+        for (uint32_t k = 0; k < kP2Rounds; k++) {
+            uint32_t nv[kP2Own];
+            bool any = false;
+#pragma unroll
+            for (uint32_t i = 0; i < kP2Own; i++) {
+                const uint32_t x = i * kP2Threads + tid, p = w0 + x;
+                const uint32_t a = J[x];
+                nv[i] = 0xffffu;
+                if (a != 0xffffu) {
+                    if ((MARK[p >> 5] >> (p & 31u)) & 1u) { const uint32_t t = w0 + a; atomicOr(&MARK[t >> 5], 1u << (t & 31u)); }
+                    nv[i] = J[a];
+                    any = true;
+                }
+            }
+            if (!__syncthreads_or(any)) break; // every path has left the window
+#pragma unroll
+            for (uint32_t i = 0; i < kP2Own; i++) J[i * kP2Threads + tid] = (uint16_t)nv[i];
+            __syncthreads();
+        }
+        // 2c. the last path node of the window leads to the entry of the next one
+        if (tid == 0) sh_last = 0;
+        __syncthreads();
+        {
+            uint32_t best = 0; // 1 + position of the highest marked bit among this lane's words of the window
+            for (uint32_t wd = (w0 >> 5) + tid; wd < (wend >> 5) && wd < nwords; wd += kP2Threads) {
+                const uint32_t v = MARK[wd];
+                if (v) best = (wd << 5) + 32u - (uint32_t)__builtin_clz(v);
+            }
+            if (best) atomicMax(&sh_last, best);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t r = sh_last - 1; // the entry itself is marked, so sh_last != 0
+            uint32_t m, L, D;
+            cx.game(r, cx.rec[r], m, L, D);
+            sh_entry = next_bit(HAS, m + L, nwords);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- 3. matches of the path: MAT bit at the match start, COV bits on the bytes behind it ----
+    uint32_t *COV = reinterpret_cast<uint32_t *>(J), *MAT = COV + kP2Words, *wbase = MAT + kP2Words; // J is dead: 8 + 8 + 8.2 KiB of its 32
+    static_assert(2 * kP2Words * 4 + (kP2Words + 1) * 4 <= kP2Win * 2, "bitmaps and bases fit in the successor table");
+    for (uint32_t i = tid; i < 2 * kP2Words; i += kP2Threads) COV[i] = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads) {
+        const uint32_t p = p0 + tid;
+        if (p < n && ((MARK[p >> 5] >> (p & 31u)) & 1u)) {
+            uint32_t m, L, D;
+            cx.game(p, cx.rec[p], m, L, D);
+            atomicOr(&MAT[m >> 5], 1u << (m & 31u));
+            const uint32_t a = m + 1, z = m + L; // [a, z)
+            for (uint32_t wd = a >> 5; wd <= (z - 1) >> 5; wd++) {
+                const uint32_t lo_b = wd == (a >> 5) ? (a & 31u) : 0u, hi_b = wd == ((z - 1) >> 5) ? ((z - 1) & 31u) : 31u;
+                atomicOr(&COV[wd], (~0u << lo_b) & (~0u >> (31u - hi_b)));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. token positions = positions not covered; word-wise exclusive prefix counts ----
+    uint32_t ntok;
+    {
+        const uint32_t w1 = tid * 2, w2 = w1 + 1; // 2048 words, two per lane
+        auto tokword = [&](uint32_t wd) -> uint32_t {
+            if (wd >= nwords) return 0;
+            uint32_t v = ~COV[wd];
+            if (wd == nwords - 1 && (n & 31u)) v &= ~0u >> (32u - (n & 31u));
+            return v;
+        };
+        const uint32_t c1 = (uint32_t)__builtin_popcount(tokword(w1)), c2 = (uint32_t)__builtin_popcount(tokword(w2));
+        uint32_t x = c1 + c2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        uint32_t b = x - (c1 + c2);
+        for (uint32_t w = 0; w < wave; w++) b += wave_tot[w];
+        wbase[w1] = b; wbase[w2] = b + c1;
+        if (tid == kP2Threads - 1) wbase[kP2Words] = b + c1 + c2;
+        __syncthreads();
+        ntok = wbase[kP2Words];
+        // COV becomes TOK (token positions) in place
+        COV[w1] = tokword(w1); COV[w2] = tokword(w2);
+        __syncthreads();
+    }
+    const uint32_t *TOK = COV;
+    auto index_of = [&](uint32_t p) { return wbase[p >> 5] + (uint32_t)__builtin_popcount(TOK[p >> 5] & ~(~0u << (p & 31u))); };
+
+    // ---- 5. tokens ----
+    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads) {
+        const uint32_t p = p0 + tid;
+        if (p >= n) continue;
+        const uint32_t bit = 1u << (p & 31u);
+        const bool is_tok = TOK[p >> 5] & bit, is_mat = MAT[p >> 5] & bit, marked = MARK[p >> 5] & bit;
+        uint2 r = make_uint2(0, 0);
+        if ((is_tok && !is_mat) || marked) r = cx.rec[p];
+        if (is_tok && !is_mat) tok[index_of(p)] = tok_lit(r.x >> 24);
+        if (marked) {
+            uint32_t m, L, D;
+            cx.game(p, r, m, L, D);
+            tok[index_of(m)] = tok_match(D, L - kMinMatch);
+        }
+    }
+
+    // ---- 6. block cuts (deflate.c:1620-1626, 1651-1656: after the 16383rd token of a block) and the stored-block veto ----
+    if (tid == 0) {
+        uint32_t nostore = 0, nblk = 0, block_start = 0;
+        for (uint32_t b = 0;; b++) {
+            const uint32_t e = (b + 1) * kBlockTokens - 1; // index of the token that fills block b
+            if (e >= ntok) break;
+            uint32_t lo_w = 0, hi_w = kP2Words; // the word holding token e: wbase[lo_w] <= e < wbase[lo_w + 1]
+            while (hi_w - lo_w > 1) { const uint32_t mid = (lo_w + hi_w) >> 1; if (wbase[mid] <= e) lo_w = mid; else hi_w = mid; }
+            uint32_t v = TOK[lo_w];
+            for (uint32_t s = e - wbase[lo_w]; s; s--) v &= v - 1;
+            const uint32_t pe = (lo_w << 5) + (uint32_t)__builtin_ctz(v);
+            const bool is_mat = (MAT[pe >> 5] >> (pe & 31u)) & 1u;
+            if (!is_mat && pe == n - 1) break; // the last byte's literal is emitted behind the loop (deflate.c:1660-1665): no cut
+            // the token is emitted while the loop stands at pe+1; a match leaves it at the next token position
+            uint32_t ns = pe + 1;
+            if (is_mat) { ns = next_bit(TOK, pe + 1, nwords); if (ns == kNone) ns = n; }
+            if (cx.slid(pe + 1) && block_start + cx.base < kWSize) nostore |= 1u << nblk;
+            nblk++; block_start = ns;
+        }
+        if ((int)n >= (int)(kWSize + kMaxDist) - (int)cx.base && block_start + cx.base < kWSize) nostore |= 1u << nblk; // the check at p == n slides too
+        meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
+    }
+}
+
+void launch_parse2(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    hipLaunchKernelGGL(parse2_kernel, dim3(g.nchunks), dim3(kP2Threads), 0, st, g, cfg, recs, tokens, meta);
+}
+
+} // namespace zgpu
