@@ -17,8 +17,8 @@
 // So the has-positions form a forest, r -> nextHas(E(r)), and the parse is the path from nextHas(0).  The kernel
 //   1. marks has(p) for all p (bitmap),
 //   2. per window of 16384 positions: computes the successor of every has-position in the window (lanes = positions),
-//      marks the path by pointer doubling (mark what the marked reach in 2^k hops, then square the table; 14 rounds), and
-//      hands the path's exit to the next window,
+//      threads the path through the window by speculative walks of 256-position blocks (see 2b below), and hands the
+//      path's exit to the next window,
 //   3. for every marked r replays the game: one match token at m, positions (m, m+len) covered,
 //   4. every position not covered is a token (a literal, or the match at m): token index = prefix count of such positions,
 //   5. writes the tokens, and derives the 16383-token block cuts and the "may not be stored" flags (trees.c:921-1016 via
@@ -28,10 +28,9 @@
 
 namespace zgpu {
 
-constexpr uint32_t kP2Threads = 1024, kP2Win = 16384, kP2Own = kP2Win / kP2Threads, kP2Rounds = 14;
-constexpr uint32_t kP2Words = kChunkMax / 32;
+constexpr uint32_t kP2Threads = 1024, kP2Win = 16384, kP2Own = kP2Win / kP2Threads, kP2Blk = kP2Win / 64;
+constexpr uint32_t kP2Words = kChunkMax / 32, kP2Batch = 8, kP2Pair = 4; // positions per lane whose loads are in flight together (one record / two)
 constexpr uint32_t kNone = 0xffffffffu;
-static_assert((1u << kP2Rounds) >= kP2Win, "doubling must cover a window");
 
 struct ParseCtx {
     const uint2 *rec;
@@ -51,17 +50,19 @@ struct ParseCtx {
         dist = d;
         return len;
     }
-    // the lazy-evaluation game from a has-position r: match start m, length, distance
-    __device__ void game(uint32_t r, uint2 rr, uint32_t &m, uint32_t &len, uint32_t &dist) const
+    // the lazy-evaluation game from a has-position r: match start m, length, distance.  rr = rec[r], rn = rec[r+1] (callers load
+    // them in batches: one load latency per position would otherwise be the whole cost of this kernel)
+    __device__ void game(uint32_t r, uint2 rr, uint2 rn, uint32_t &m, uint32_t &len, uint32_t &dist) const
     {
         uint32_t L, D = 0;
         L = take(r, kMinMatch - 1, rr, D);
         uint32_t q = r + 1;
         for (;;) { // a match of L >= 3 bytes at q-1 ends inside the chunk, so q <= n-2 has a record
             uint32_t D2 = 0;
-            const uint32_t L2 = take(q, L, rec[q], D2);
+            const uint32_t L2 = take(q, L, rn, D2);
             if (L2 <= L) break; // (take returns 2 when it keeps the match in hand)
             L = L2; D = D2; q++;
+            rn = rec[q];
         }
         m = q - 1; len = L; dist = D;
     }
@@ -76,13 +77,14 @@ __device__ inline uint32_t next_bit(const uint32_t *bits, uint32_t x, uint32_t n
     return (w << 5) + (uint32_t)__builtin_ctz(v);
 }
 
-__global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
+__global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
                                                             ChunkMeta *meta)
 {
     __shared__ __attribute__((aligned(16))) uint16_t J[kP2Win]; // successor of a has-position, window-relative; later COV | MAT | word bases
     __shared__ uint32_t HAS[kP2Words], MARK[kP2Words];
     __shared__ uint32_t wave_tot[kP2Threads / 64];
-    __shared__ uint32_t sh_entry, sh_last;
+    __shared__ uint32_t VIS[kP2Win / 32], EXITS[64];
+    __shared__ uint32_t sh_entry;
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
@@ -97,16 +99,23 @@ __global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCf
         cx.slide_at = a > b ? a : b;
     }
     uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint8_t *src = g.in + lo;
     const uint32_t nwords = (n + 31) >> 5;
 
     // ---- 1. has(p) ----
     for (uint32_t i = tid; i < kP2Words; i += kP2Threads) MARK[i] = 0;
-    for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads) {
-        const uint32_t p = p0 + tid;
-        bool h = false;
-        if (p < n) { uint32_t d; h = cx.take(p, kMinMatch - 1, cx.rec[p], d) >= kMinMatch; }
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(h);
-        if (lane == 0) { HAS[(p0 >> 5) + 2 * wave] = (uint32_t)b; HAS[(p0 >> 5) + 2 * wave + 1] = (uint32_t)(b >> 32); }
+    for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads * kP2Batch) {
+        uint2 rv[kP2Batch];
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Batch; u++) { const uint32_t p = p0 + u * kP2Threads + tid; rv[u] = p < n ? cx.rec[p] : make_uint2(0, 0); }
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Batch; u++) {
+            const uint32_t pw = p0 + u * kP2Threads, p = pw + tid;
+            uint32_t d;
+            const bool h = p < n && cx.take(p, kMinMatch - 1, rv[u], d) >= kMinMatch;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(h);
+            if (lane == 0) { HAS[(pw >> 5) + 2 * wave] = (uint32_t)b; HAS[(pw >> 5) + 2 * wave + 1] = (uint32_t)(b >> 32); }
+        }
     }
     __syncthreads();
 
@@ -119,57 +128,83 @@ __global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCf
         if (entry == kNone) break;       // (uniform) no match from here to the end
         if (entry >= wend) continue;     // (uniform) the path jumps over this window
         // 2a. successors
-#pragma unroll 4
-        for (uint32_t i = 0; i < kP2Own; i++) {
-            const uint32_t x = i * kP2Threads + tid, p = w0 + x;
-            uint32_t succ = 0xffffu;
-            if (p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u)) {
-                uint32_t m, L, D;
-                cx.game(p, cx.rec[p], m, L, D);
-                const uint32_t t = next_bit(HAS, m + L, nwords);
-                if (t < wend) succ = t - w0;
-            }
-            J[x] = (uint16_t)succ;
-        }
-        if (tid == 0) atomicOr(&MARK[entry >> 5], 1u << (entry & 31u));
-        __syncthreads();
-        // 2b. doubling: after round k the marked set is the first 2^(k+1) path nodes of the window
-        for (uint32_t k = 0; k < kP2Rounds; k++) {
-            uint32_t nv[kP2Own];
-            bool any = false;
+        for (uint32_t ib = 0; ib < kP2Own; ib += kP2Pair) {
+            uint2 ra[kP2Pair], rb[kP2Pair];
+            bool hs[kP2Pair];
 #pragma unroll
-            for (uint32_t i = 0; i < kP2Own; i++) {
-                const uint32_t x = i * kP2Threads + tid, p = w0 + x;
-                const uint32_t a = J[x];
-                nv[i] = 0xffffu;
-                if (a != 0xffffu) {
-                    if ((MARK[p >> 5] >> (p & 31u)) & 1u) { const uint32_t t = w0 + a; atomicOr(&MARK[t >> 5], 1u << (t & 31u)); }
-                    nv[i] = J[a];
-                    any = true;
+            for (uint32_t u = 0; u < kP2Pair; u++) {
+                const uint32_t p = w0 + (ib + u) * kP2Threads + tid;
+                hs[u] = p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u);
+                ra[u] = rb[u] = make_uint2(0, 0);
+                if (hs[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kP2Pair; u++) {
+                const uint32_t x = (ib + u) * kP2Threads + tid, p = w0 + x;
+                uint32_t succ = 0xffffu;
+                if (hs[u]) {
+                    uint32_t m, L, D;
+                    cx.game(p, ra[u], rb[u], m, L, D);
+                    const uint32_t t = next_bit(HAS, m + L, nwords);
+                    if (t < wend) succ = t - w0;
                 }
+                J[x] = (uint16_t)succ;
             }
-            if (!__syncthreads_or(any)) break; // every path has left the window
+        }
+        for (uint32_t i = tid; i < kP2Win / 32; i += kP2Threads) VIS[i] = 0;
+        __syncthreads();
+        // 2b. The path through the window, without walking it end to end: parses started at different positions fall into
+        // step with each other after a match or two, so every block of 256 positions is walked speculatively from its first
+        // has-position (64 lanes, ~30 dependent hops each), and the true path is then threaded through the blocks: where it
+        // enters a block on a node the speculative walk visited, the rest of that walk IS the path there; where not, the
+        // block is re-walked from the true entry.
+        if (wave == 0) {
+            const uint32_t bs = w0 + lane * kP2Blk, be = bs + kP2Blk;
+            uint32_t x = next_bit(HAS, bs, nwords); // exit of an empty block: the first node behind it
+            if (x != kNone && x >= wend) x = kNone;
+            while (x != kNone && x < be) {
+                VIS[(x - w0) >> 5] |= 1u << (x & 31u); // the words of a block belong to its lane
+                const uint32_t a2 = J[x - w0];
+                x = a2 == 0xffffu ? kNone : w0 + a2;
+            }
+            EXITS[lane] = x; // first path node behind the block if the path enters the block on a visited node; kNone: leaves the window
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // VIS and EXITS of the other lanes (LDS, same wave: in order)
+            __builtin_amdgcn_wave_barrier();
+            uint32_t cur = entry, last = entry;
+            while (cur != kNone) { // wave-uniform
+                const uint32_t blk = (cur - w0) / kP2Blk, be2 = w0 + (blk + 1) * kP2Blk;
+                // from the true entry until the path meets the block's speculative walk (at once, or after a match or two)
+                uint32_t x2 = cur;
+                while (x2 != kNone && x2 < be2 && !((VIS[(x2 - w0) >> 5] >> (x2 & 31u)) & 1u)) {
+                    last = x2;
+                    if (lane == 0) MARK[x2 >> 5] |= 1u << (x2 & 31u);
+                    const uint32_t a2 = J[x2 - w0];
+                    x2 = a2 == 0xffffu ? kNone : w0 + a2;
+                }
+                if (x2 != kNone && x2 < be2) { // met at x2: from here on the speculative walk is the path
+                    const uint32_t cw = (x2 - w0) >> 5;
+                    uint32_t hi = 0;
+                    if (lane < kP2Blk / 32) {
+                        const uint32_t wd = blk * (kP2Blk / 32) + lane;
+                        uint32_t v = VIS[wd];
+                        if (v) hi = (wd << 5) + 32u - (uint32_t)__builtin_clz(v); // 1 + the last visited node of the block (window-relative)
+                        if (wd < cw) v = 0; else if (wd == cw) v &= ~0u << (x2 & 31u);
+                        if (v) MARK[(w0 >> 5) + wd] |= v;
+                    }
 #pragma unroll
-            for (uint32_t i = 0; i < kP2Own; i++) J[i * kP2Threads + tid] = (uint16_t)nv[i];
-            __syncthreads();
-        }
-        // 2c. the last path node of the window leads to the entry of the next one
-        if (tid == 0) sh_last = 0;
-        __syncthreads();
-        {
-            uint32_t best = 0; // 1 + position of the highest marked bit among this lane's words of the window
-            for (uint32_t wd = (w0 >> 5) + tid; wd < (wend >> 5) && wd < nwords; wd += kP2Threads) {
-                const uint32_t v = MARK[wd];
-                if (v) best = (wd << 5) + 32u - (uint32_t)__builtin_clz(v);
+                    for (int d = 1; d < 8; d <<= 1) { const uint32_t y = __shfl_xor(hi, d); if (y > hi) hi = y; }
+                    last = w0 + hi - 1;
+                    x2 = EXITS[blk];
+                }
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane(x2);
+                last = (uint32_t)__builtin_amdgcn_readfirstlane(last);
             }
-            if (best) atomicMax(&sh_last, best);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t r = sh_last - 1; // the entry itself is marked, so sh_last != 0
-            uint32_t m, L, D;
-            cx.game(r, cx.rec[r], m, L, D);
-            sh_entry = next_bit(HAS, m + L, nwords);
+            // 2c. the last path node of the window leads to the entry of the next one
+            if (lane == 0) {
+                uint32_t m, L, D;
+                cx.game(last, cx.rec[last], cx.rec[last + 1], m, L, D);
+                sh_entry = next_bit(HAS, m + L, nwords);
+            }
         }
         __syncthreads();
     }
@@ -180,11 +215,22 @@ __global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCf
     static_assert(2 * kP2Words * 4 + (kP2Words + 1) * 4 <= kP2Win * 2, "bitmaps and bases fit in the successor table");
     for (uint32_t i = tid; i < 2 * kP2Words; i += kP2Threads) COV[i] = 0;
     __syncthreads();
-    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads) {
-        const uint32_t p = p0 + tid;
-        if (p < n && ((MARK[p >> 5] >> (p & 31u)) & 1u)) {
+    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads * kP2Pair) {
+        uint2 ra[kP2Pair], rb[kP2Pair];
+        bool mk[kP2Pair];
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Pair; u++) {
+            const uint32_t p = p0 + u * kP2Threads + tid;
+            mk[u] = p < n && ((MARK[p >> 5] >> (p & 31u)) & 1u);
+            ra[u] = rb[u] = make_uint2(0, 0);
+            if (mk[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Pair; u++) {
+            if (!mk[u]) continue;
+            const uint32_t p = p0 + u * kP2Threads + tid;
             uint32_t m, L, D;
-            cx.game(p, cx.rec[p], m, L, D);
+            cx.game(p, ra[u], rb[u], m, L, D);
             atomicOr(&MAT[m >> 5], 1u << (m & 31u));
             const uint32_t a = m + 1, z = m + L; // [a, z)
             for (uint32_t wd = a >> 5; wd <= (z - 1) >> 5; wd++) {
@@ -225,18 +271,28 @@ __global__ void __launch_bounds__(kP2Threads) parse2_kernel(ChunkGeom g, LevelCf
     auto index_of = [&](uint32_t p) { return wbase[p >> 5] + (uint32_t)__builtin_popcount(TOK[p >> 5] & ~(~0u << (p & 31u))); };
 
     // ---- 5. tokens ----
-    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads) {
-        const uint32_t p = p0 + tid;
-        if (p >= n) continue;
-        const uint32_t bit = 1u << (p & 31u);
-        const bool is_tok = TOK[p >> 5] & bit, is_mat = MAT[p >> 5] & bit, marked = MARK[p >> 5] & bit;
-        uint2 r = make_uint2(0, 0);
-        if ((is_tok && !is_mat) || marked) r = cx.rec[p];
-        if (is_tok && !is_mat) tok[index_of(p)] = tok_lit(r.x >> 24);
-        if (marked) {
-            uint32_t m, L, D;
-            cx.game(p, r, m, L, D);
-            tok[index_of(m)] = tok_match(D, L - kMinMatch);
+    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads * kP2Pair) {
+        uint2 ra[kP2Pair], rb[kP2Pair];
+        uint32_t lit[kP2Pair];
+        bool mk[kP2Pair], li[kP2Pair];
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Pair; u++) {
+            const uint32_t p = p0 + u * kP2Threads + tid, bit = 1u << (p & 31u);
+            mk[u] = p < n && (MARK[p >> 5] & bit);
+            li[u] = p < n && (TOK[p >> 5] & bit) && !(MAT[p >> 5] & bit);
+            ra[u] = rb[u] = make_uint2(0, 0); lit[u] = 0;
+            if (mk[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
+            if (li[u]) lit[u] = src[p];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kP2Pair; u++) {
+            const uint32_t p = p0 + u * kP2Threads + tid;
+            if (li[u]) tok[index_of(p)] = tok_lit(lit[u]);
+            if (mk[u]) {
+                uint32_t m, L, D;
+                cx.game(p, ra[u], rb[u], m, L, D);
+                tok[index_of(m)] = tok_match(D, L - kMinMatch);
+            }
         }
     }
 
