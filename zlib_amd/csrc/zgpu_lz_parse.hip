@@ -19,10 +19,10 @@
 //   2. per window of 16384 positions: computes the successor of every has-position in the window (lanes = positions),
 //      threads the path through the window by speculative walks of 256-position blocks (see 2b below), and hands the
 //      path's exit to the next window,
-//   3. for every marked r replays the game: one match token at m, positions (m, m+len) covered,
-//   4. every position not covered is a token (a literal, or the match at m): token index = prefix count of such positions,
-//   5. writes the tokens, and derives the 16383-token block cuts and the "may not be stored" flags (trees.c:921-1016 via
-//      deflate.c FLUSH_BLOCK_ONLY) from token indices.
+//      then, still per window: every node on the path contributes one match token at m and covers (m, m+len); every
+//      position not covered is a token (a literal, or the match at m) whose index is the prefix count of such positions,
+//   3. derives the 16383-token block cuts and the "may not be stored" flags (trees.c:921-1016 via deflate.c
+//      FLUSH_BLOCK_ONLY) from token indices.
 // Output is identical to parse_kernel's: tokens, ntok, nostore, in_bytes.
 #include "zgpu_common.h"
 
@@ -77,13 +77,30 @@ __device__ inline uint32_t next_bit(const uint32_t *bits, uint32_t x, uint32_t n
     return (w << 5) + (uint32_t)__builtin_ctz(v);
 }
 
-__global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
-                                                            ChunkMeta *meta)
+#ifdef ZGPU_P2_TIME // debug build only (scripts/p2_time.py): cycles per phase, summed over workgroups (lane 0's clock)
+__device__ unsigned long long p2_time[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_p2_time(unsigned long long *out, int reset)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t J[kP2Win]; // successor of a has-position, window-relative; later COV | MAT | word bases
-    __shared__ uint32_t HAS[kP2Words], MARK[kP2Words];
-    __shared__ uint32_t wave_tot[kP2Threads / 64];
+    unsigned long long z[8] = {};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(p2_time), sizeof z);
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(p2_time), z, sizeof z);
+}
+#define P2_T(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&p2_time[i], t_ - t_prev); t_prev = t_; } } while (0)
+#define P2_T0() unsigned long long t_prev = wall_clock64()
+#else
+#define P2_T(i) do { } while (0)
+#define P2_T0() do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
+                                                               ChunkMeta *meta)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t J[kP2Win]; // successor of a has-position, window-relative (0xffff: leaves the window)
+    __shared__ uint32_t HAS[kP2Words], MARK[kP2Words], COV[kP2Words], MAT[kP2Words]; // per position: has a match / on the path / inside a match
+                                                                                    // (later: is a token) / starts an emitted match
+    __shared__ uint32_t wbase[kP2Words + 1];                   // tokens in front of each 32-position word
     __shared__ uint32_t VIS[kP2Win / 32], EXITS[64];
+    __shared__ uint32_t wave_tot[kP2Threads / 64];
     __shared__ uint32_t sh_entry;
     const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t lo; uint32_t n;
@@ -102,8 +119,9 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
     const uint8_t *src = g.in + lo;
     const uint32_t nwords = (n + 31) >> 5;
 
+    P2_T0();
     // ---- 1. has(p) ----
-    for (uint32_t i = tid; i < kP2Words; i += kP2Threads) MARK[i] = 0;
+    for (uint32_t i = tid; i < kP2Words; i += kP2Threads) { MARK[i] = 0; COV[i] = 0; MAT[i] = 0; }
     for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads * kP2Batch) {
         uint2 rv[kP2Batch];
 #pragma unroll
@@ -118,194 +136,190 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
         }
     }
     __syncthreads();
-
-    // ---- 2. the path, window by window ----
     if (tid == 0) sh_entry = next_bit(HAS, 0, nwords);
     __syncthreads();
+    P2_T(0);
+
+    const uint32_t *TOK = COV; // a window's COV words turn into its token words in step C
+    auto index_of = [&](uint32_t p) { return wbase[p >> 5] + (uint32_t)__builtin_popcount(TOK[p >> 5] & ~(~0u << (p & 31u))); };
+    uint32_t tokbase = 0;                   // tokens in front of the window (uniform)
+    uint32_t def_m = kNone, def_tok = 0;    // a match token whose position lies in the next window
+
+    // ---- 2. window by window: path, matches, token indices, tokens ----
     for (uint32_t w0 = 0; w0 < n; w0 += kP2Win) {
         const uint32_t wend = w0 + kP2Win;
-        uint32_t entry = sh_entry;
-        if (entry == kNone) break;       // (uniform) no match from here to the end
-        if (entry >= wend) continue;     // (uniform) the path jumps over this window
-        // 2a. successors
-        for (uint32_t ib = 0; ib < kP2Own; ib += kP2Pair) {
-            uint2 ra[kP2Pair], rb[kP2Pair];
-            bool hs[kP2Pair];
+        const uint32_t entry = sh_entry;
+        uint32_t gm[kP2Own]; // the game of this lane's has-positions: (m - p) << 24 | len << 15 | dist; 0: none
 #pragma unroll
-            for (uint32_t u = 0; u < kP2Pair; u++) {
-                const uint32_t p = w0 + (ib + u) * kP2Threads + tid;
-                hs[u] = p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u);
-                ra[u] = rb[u] = make_uint2(0, 0);
-                if (hs[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
-            }
+        for (uint32_t i = 0; i < kP2Own; i++) gm[i] = 0;
+        if (entry != kNone && entry < wend) { // (uniform) the path has nodes in this window
+            // A1. successors of all has-positions of the window
 #pragma unroll
-            for (uint32_t u = 0; u < kP2Pair; u++) {
-                const uint32_t x = (ib + u) * kP2Threads + tid, p = w0 + x;
-                uint32_t succ = 0xffffu;
-                if (hs[u]) {
-                    uint32_t m, L, D;
-                    cx.game(p, ra[u], rb[u], m, L, D);
-                    const uint32_t t = next_bit(HAS, m + L, nwords);
-                    if (t < wend) succ = t - w0;
+            for (uint32_t ib = 0; ib < kP2Own; ib += kP2Pair) {
+                uint2 ra[kP2Pair], rb[kP2Pair];
+                bool hs[kP2Pair];
+#pragma unroll
+                for (uint32_t u = 0; u < kP2Pair; u++) {
+                    const uint32_t p = w0 + (ib + u) * kP2Threads + tid;
+                    hs[u] = p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u);
+                    ra[u] = rb[u] = make_uint2(0, 0);
+                    if (hs[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
                 }
-                J[x] = (uint16_t)succ;
-            }
-        }
-        for (uint32_t i = tid; i < kP2Win / 32; i += kP2Threads) VIS[i] = 0;
-        __syncthreads();
-        // 2b. The path through the window, without walking it end to end: parses started at different positions fall into
-        // step with each other after a match or two, so every block of 256 positions is walked speculatively from its first
-        // has-position (64 lanes, ~30 dependent hops each), and the true path is then threaded through the blocks: where it
-        // enters a block on a node the speculative walk visited, the rest of that walk IS the path there; where not, the
-        // block is re-walked from the true entry.
-        if (wave == 0) {
-            const uint32_t bs = w0 + lane * kP2Blk, be = bs + kP2Blk;
-            uint32_t x = next_bit(HAS, bs, nwords); // exit of an empty block: the first node behind it
-            if (x != kNone && x >= wend) x = kNone;
-            while (x != kNone && x < be) {
-                VIS[(x - w0) >> 5] |= 1u << (x & 31u); // the words of a block belong to its lane
-                const uint32_t a2 = J[x - w0];
-                x = a2 == 0xffffu ? kNone : w0 + a2;
-            }
-            EXITS[lane] = x; // first path node behind the block if the path enters the block on a visited node; kNone: leaves the window
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // VIS and EXITS of the other lanes (LDS, same wave: in order)
-            __builtin_amdgcn_wave_barrier();
-            uint32_t cur = entry, last = entry;
-            while (cur != kNone) { // wave-uniform
-                const uint32_t blk = (cur - w0) / kP2Blk, be2 = w0 + (blk + 1) * kP2Blk;
-                // from the true entry until the path meets the block's speculative walk (at once, or after a match or two)
-                uint32_t x2 = cur;
-                while (x2 != kNone && x2 < be2 && !((VIS[(x2 - w0) >> 5] >> (x2 & 31u)) & 1u)) {
-                    last = x2;
-                    if (lane == 0) MARK[x2 >> 5] |= 1u << (x2 & 31u);
-                    const uint32_t a2 = J[x2 - w0];
-                    x2 = a2 == 0xffffu ? kNone : w0 + a2;
-                }
-                if (x2 != kNone && x2 < be2) { // met at x2: from here on the speculative walk is the path
-                    const uint32_t cw = (x2 - w0) >> 5;
-                    uint32_t hi = 0;
-                    if (lane < kP2Blk / 32) {
-                        const uint32_t wd = blk * (kP2Blk / 32) + lane;
-                        uint32_t v = VIS[wd];
-                        if (v) hi = (wd << 5) + 32u - (uint32_t)__builtin_clz(v); // 1 + the last visited node of the block (window-relative)
-                        if (wd < cw) v = 0; else if (wd == cw) v &= ~0u << (x2 & 31u);
-                        if (v) MARK[(w0 >> 5) + wd] |= v;
+#pragma unroll
+                for (uint32_t u = 0; u < kP2Pair; u++) {
+                    const uint32_t x = (ib + u) * kP2Threads + tid, p = w0 + x;
+                    uint32_t succ = 0xffffu;
+                    if (hs[u]) {
+                        uint32_t m, L, D;
+                        cx.game(p, ra[u], rb[u], m, L, D);
+                        gm[ib + u] = ((m - p) << 24) | (L << 15) | D;
+                        const uint32_t t = next_bit(HAS, m + L, nwords);
+                        if (t < wend) succ = t - w0;
                     }
-#pragma unroll
-                    for (int d = 1; d < 8; d <<= 1) { const uint32_t y = __shfl_xor(hi, d); if (y > hi) hi = y; }
-                    last = w0 + hi - 1;
-                    x2 = EXITS[blk];
+                    J[x] = (uint16_t)succ;
                 }
-                cur = (uint32_t)__builtin_amdgcn_readfirstlane(x2);
-                last = (uint32_t)__builtin_amdgcn_readfirstlane(last);
             }
-            // 2c. the last path node of the window leads to the entry of the next one
-            if (lane == 0) {
-                uint32_t m, L, D;
-                cx.game(last, cx.rec[last], cx.rec[last + 1], m, L, D);
-                sh_entry = next_bit(HAS, m + L, nwords);
+            __syncthreads();
+            P2_T(1);
+            // A2. The path through the window, without walking it end to end: parses started at different positions fall into
+            // step with each other after a match or two, so every block of 256 positions is walked speculatively from its first
+            // has-position (64 lanes, ~30 dependent hops each), and the true path is then threaded through the blocks: it is
+            // walked from where it enters a block until it meets the block's speculative walk; from there on that walk IS the path.
+            if (wave == 0) {
+                const uint32_t bs = w0 + lane * kP2Blk, be = bs + kP2Blk;
+                uint32_t v8[kP2Blk / 32];
+#pragma unroll
+                for (uint32_t j = 0; j < kP2Blk / 32; j++) v8[j] = 0;
+                uint32_t x = next_bit(HAS, bs, nwords); // (an empty block's exit: the first node behind it)
+                if (x != kNone && x >= wend) x = kNone;
+                while (x != kNone && x < be) {
+                    const uint32_t wi = (x - bs) >> 5, bit = 1u << (x & 31u);
+#pragma unroll
+                    for (uint32_t j = 0; j < kP2Blk / 32; j++) v8[j] |= wi == j ? bit : 0u;
+                    const uint32_t a2 = J[x - w0];
+                    x = a2 == 0xffffu ? kNone : w0 + a2;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kP2Blk / 32; j++) VIS[lane * (kP2Blk / 32) + j] = v8[j];
+                EXITS[lane] = x; // where the block's walk leaves the block (kNone: leaves the window)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // other lanes' VIS and EXITS (LDS, same wave: in order)
+                __builtin_amdgcn_wave_barrier();
+                uint32_t cur = entry, last = entry, met_blk = kNone; // wave-uniform
+                while (cur != kNone) {
+                    const uint32_t blk = (cur - w0) / kP2Blk, be2 = w0 + (blk + 1) * kP2Blk;
+                    uint32_t x2 = cur;
+                    met_blk = kNone;
+                    while (x2 != kNone && x2 < be2 && !((VIS[(x2 - w0) >> 5] >> (x2 & 31u)) & 1u)) {
+                        last = x2;
+                        if (lane == 0) atomicOr(&MARK[x2 >> 5], 1u << (x2 & 31u));
+                        const uint32_t a2 = J[x2 - w0];
+                        x2 = a2 == 0xffffu ? kNone : w0 + a2;
+                    }
+                    if (x2 != kNone && x2 < be2) { // met at x2
+                        const uint32_t cw = (x2 - w0) >> 5;
+                        if (lane < kP2Blk / 32) {
+                            const uint32_t wd = blk * (kP2Blk / 32) + lane;
+                            uint32_t v = VIS[wd];
+                            if (wd < cw) v = 0; else if (wd == cw) v &= ~0u << (x2 & 31u);
+                            if (v) atomicOr(&MARK[(w0 >> 5) + wd], v);
+                        }
+                        met_blk = blk;
+                        x2 = EXITS[blk];
+                    }
+                    cur = (uint32_t)__builtin_amdgcn_readfirstlane(x2);
+                    last = (uint32_t)__builtin_amdgcn_readfirstlane(last);
+                    met_blk = (uint32_t)__builtin_amdgcn_readfirstlane(met_blk);
+                }
+                if (met_blk != kNone) { // the path ended inside a speculative walk: its last node is that block's last visited one
+                    uint32_t hi = 0;
+                    for (uint32_t j = 0; j < kP2Blk / 32; j++) { const uint32_t v = VIS[met_blk * (kP2Blk / 32) + j]; if (v) hi = ((met_blk * (kP2Blk / 32) + j) << 5) + 32u - (uint32_t)__builtin_clz(v); }
+                    last = w0 + hi - 1;
+                }
+                if (lane == 0) { // the last path node of the window leads to the entry of the next one
+                    uint32_t m, L, D;
+                    cx.game(last, cx.rec[last], cx.rec[last + 1], m, L, D);
+                    sh_entry = next_bit(HAS, m + L, nwords);
+                }
+            }
+            __syncthreads();
+            P2_T(2);
+            // B. matches of the path: MAT bit at the match start, COV bits on the bytes behind it (they may reach into the next window)
+#pragma unroll
+            for (uint32_t i = 0; i < kP2Own; i++) {
+                const uint32_t p = w0 + i * kP2Threads + tid;
+                if (gm[i] && ((MARK[p >> 5] >> (p & 31u)) & 1u)) {
+                    const uint32_t m = p + (gm[i] >> 24), L = (gm[i] >> 15) & 511u;
+                    atomicOr(&MAT[m >> 5], 1u << (m & 31u));
+                    const uint32_t a = m + 1, z = m + L; // [a, z)
+                    for (uint32_t wd = a >> 5; wd <= (z - 1) >> 5; wd++) {
+                        const uint32_t lo_b = wd == (a >> 5) ? (a & 31u) : 0u, hi_b = wd == ((z - 1) >> 5) ? ((z - 1) & 31u) : 31u;
+                        atomicOr(&COV[wd], (~0u << lo_b) & (~0u >> (31u - hi_b)));
+                    }
+                } else gm[i] = 0;
             }
         }
         __syncthreads();
+        P2_T(3);
+        // C. token positions of the window = positions not inside a match; exclusive prefix counts per word (512 words: lanes 0..511)
+        {
+            const uint32_t wd = (w0 >> 5) + tid;
+            uint32_t tw = 0;
+            if (tid < kP2Win / 32 && wd < nwords) {
+                tw = ~COV[wd];
+                if (wd == nwords - 1 && (n & 31u)) tw &= ~0u >> (32u - (n & 31u));
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(tw);
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+            if (lane == 63) wave_tot[wave] = x;
+            __syncthreads();
+            uint32_t b = tokbase + x - cnt, tot = 0;
+            for (uint32_t w = 0; w < kP2Win / 32 / 64; w++) { const uint32_t t = wave_tot[w]; tot += t; if (w < wave) b += t; }
+            if (tid < kP2Win / 32) { wbase[wd] = b; COV[wd] = tw; } // (wd < kP2Words always; words past nwords hold no tokens)
+            tokbase += tot;
+            __syncthreads();
+        }
+        P2_T(4);
+        // D. tokens of the window
+        if (def_m != kNone) { tok[index_of(def_m)] = def_tok; def_m = kNone; }
+#pragma unroll
+        for (uint32_t ib = 0; ib < kP2Own; ib += kP2Batch) {
+            uint32_t lit[kP2Batch];
+            bool li[kP2Batch];
+#pragma unroll
+            for (uint32_t u = 0; u < kP2Batch; u++) {
+                const uint32_t p = w0 + (ib + u) * kP2Threads + tid, bit = 1u << (p & 31u);
+                li[u] = p < n && (TOK[p >> 5] & bit) && !(MAT[p >> 5] & bit);
+                lit[u] = 0;
+                if (li[u]) lit[u] = src[p];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kP2Batch; u++) {
+                const uint32_t p = w0 + (ib + u) * kP2Threads + tid;
+                if (li[u]) tok[index_of(p)] = tok_lit(lit[u]);
+                const uint32_t gv = gm[ib + u];
+                if (gv) {
+                    const uint32_t m = p + (gv >> 24), t = tok_match(gv & 32767u, ((gv >> 15) & 511u) - kMinMatch);
+                    if (m < wend) tok[index_of(m)] = t; else { def_m = m; def_tok = t; } // (at most one per lane: m - p < 1024)
+                }
+            }
+        }
     }
+    P2_T(5);
+    const uint32_t ntok = tokbase, nw_done = ((n + kP2Win - 1) / kP2Win) * (kP2Win / 32); // words that have a wbase entry
     __syncthreads();
 
-    // ---- 3. matches of the path: MAT bit at the match start, COV bits on the bytes behind it ----
-    uint32_t *COV = reinterpret_cast<uint32_t *>(J), *MAT = COV + kP2Words, *wbase = MAT + kP2Words; // J is dead: 8 + 8 + 8.2 KiB of its 32
-    static_assert(2 * kP2Words * 4 + (kP2Words + 1) * 4 <= kP2Win * 2, "bitmaps and bases fit in the successor table");
-    for (uint32_t i = tid; i < 2 * kP2Words; i += kP2Threads) COV[i] = 0;
-    __syncthreads();
-    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads * kP2Pair) {
-        uint2 ra[kP2Pair], rb[kP2Pair];
-        bool mk[kP2Pair];
-#pragma unroll
-        for (uint32_t u = 0; u < kP2Pair; u++) {
-            const uint32_t p = p0 + u * kP2Threads + tid;
-            mk[u] = p < n && ((MARK[p >> 5] >> (p & 31u)) & 1u);
-            ra[u] = rb[u] = make_uint2(0, 0);
-            if (mk[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kP2Pair; u++) {
-            if (!mk[u]) continue;
-            const uint32_t p = p0 + u * kP2Threads + tid;
-            uint32_t m, L, D;
-            cx.game(p, ra[u], rb[u], m, L, D);
-            atomicOr(&MAT[m >> 5], 1u << (m & 31u));
-            const uint32_t a = m + 1, z = m + L; // [a, z)
-            for (uint32_t wd = a >> 5; wd <= (z - 1) >> 5; wd++) {
-                const uint32_t lo_b = wd == (a >> 5) ? (a & 31u) : 0u, hi_b = wd == ((z - 1) >> 5) ? ((z - 1) & 31u) : 31u;
-                atomicOr(&COV[wd], (~0u << lo_b) & (~0u >> (31u - hi_b)));
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 4. token positions = positions not covered; word-wise exclusive prefix counts ----
-    uint32_t ntok;
-    {
-        const uint32_t w1 = tid * 2, w2 = w1 + 1; // 2048 words, two per lane
-        auto tokword = [&](uint32_t wd) -> uint32_t {
-            if (wd >= nwords) return 0;
-            uint32_t v = ~COV[wd];
-            if (wd == nwords - 1 && (n & 31u)) v &= ~0u >> (32u - (n & 31u));
-            return v;
-        };
-        const uint32_t c1 = (uint32_t)__builtin_popcount(tokword(w1)), c2 = (uint32_t)__builtin_popcount(tokword(w2));
-        uint32_t x = c1 + c2;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
-        if (lane == 63) wave_tot[wave] = x;
-        __syncthreads();
-        uint32_t b = x - (c1 + c2);
-        for (uint32_t w = 0; w < wave; w++) b += wave_tot[w];
-        wbase[w1] = b; wbase[w2] = b + c1;
-        if (tid == kP2Threads - 1) wbase[kP2Words] = b + c1 + c2;
-        __syncthreads();
-        ntok = wbase[kP2Words];
-        // COV becomes TOK (token positions) in place
-        COV[w1] = tokword(w1); COV[w2] = tokword(w2);
-        __syncthreads();
-    }
-    const uint32_t *TOK = COV;
-    auto index_of = [&](uint32_t p) { return wbase[p >> 5] + (uint32_t)__builtin_popcount(TOK[p >> 5] & ~(~0u << (p & 31u))); };
-
-    // ---- 5. tokens ----
-    for (uint32_t p0 = 0; p0 < n; p0 += kP2Threads * kP2Pair) {
-        uint2 ra[kP2Pair], rb[kP2Pair];
-        uint32_t lit[kP2Pair];
-        bool mk[kP2Pair], li[kP2Pair];
-#pragma unroll
-        for (uint32_t u = 0; u < kP2Pair; u++) {
-            const uint32_t p = p0 + u * kP2Threads + tid, bit = 1u << (p & 31u);
-            mk[u] = p < n && (MARK[p >> 5] & bit);
-            li[u] = p < n && (TOK[p >> 5] & bit) && !(MAT[p >> 5] & bit);
-            ra[u] = rb[u] = make_uint2(0, 0); lit[u] = 0;
-            if (mk[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
-            if (li[u]) lit[u] = src[p];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kP2Pair; u++) {
-            const uint32_t p = p0 + u * kP2Threads + tid;
-            if (li[u]) tok[index_of(p)] = tok_lit(lit[u]);
-            if (mk[u]) {
-                uint32_t m, L, D;
-                cx.game(p, ra[u], rb[u], m, L, D);
-                tok[index_of(m)] = tok_match(D, L - kMinMatch);
-            }
-        }
-    }
-
-    // ---- 6. block cuts (deflate.c:1620-1626, 1651-1656: after the 16383rd token of a block) and the stored-block veto ----
+    // ---- 3. block cuts (deflate.c:1620-1626, 1651-1656: after the 16383rd token of a block) and the stored-block veto ----
     if (tid == 0) {
         uint32_t nostore = 0, nblk = 0, block_start = 0;
         for (uint32_t b = 0;; b++) {
             const uint32_t e = (b + 1) * kBlockTokens - 1; // index of the token that fills block b
             if (e >= ntok) break;
-            uint32_t lo_w = 0, hi_w = kP2Words; // the word holding token e: wbase[lo_w] <= e < wbase[lo_w + 1]
+            uint32_t lo_w = 0, hi_w = nw_done; // the word holding token e: wbase[lo_w] <= e < wbase[lo_w + 1]
             while (hi_w - lo_w > 1) { const uint32_t mid = (lo_w + hi_w) >> 1; if (wbase[mid] <= e) lo_w = mid; else hi_w = mid; }
             uint32_t v = TOK[lo_w];
-            for (uint32_t s = e - wbase[lo_w]; s; s--) v &= v - 1;
+            for (uint32_t s2 = e - wbase[lo_w]; s2; s2--) v &= v - 1;
             const uint32_t pe = (lo_w << 5) + (uint32_t)__builtin_ctz(v);
             const bool is_mat = (MAT[pe >> 5] >> (pe & 31u)) & 1u;
             if (!is_mat && pe == n - 1) break; // the last byte's literal is emitted behind the loop (deflate.c:1660-1665): no cut
@@ -318,6 +332,7 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
         if ((int)n >= (int)(kWSize + kMaxDist) - (int)cx.base && block_start + cx.base < kWSize) nostore |= 1u << nblk; // the check at p == n slides too
         meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
     }
+    P2_T(6);
 }
 
 void launch_parse2(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
