@@ -28,8 +28,8 @@
 
 namespace zgpu {
 
-constexpr uint32_t kP2Threads = 1024, kP2Win = 16384, kP2Own = kP2Win / kP2Threads, kP2Blk = kP2Win / 64;
-constexpr uint32_t kP2Words = kChunkMax / 32, kP2Batch = 8, kP2Pair = 4; // positions per lane whose loads are in flight together (one record / two)
+constexpr uint32_t kP2Threads = 1024, kP2Win = 8192, kP2Own = kP2Win / kP2Threads, kP2Blk = kP2Win / 64;
+constexpr uint32_t kP2Words = kChunkMax / 32, kP2Batch = 8, kP2Pair = 4, kP2Over = 8; // positions per lane whose loads are in flight together; overhang of a wave's games
 constexpr uint32_t kNone = 0xffffffffu;
 
 struct ParseCtx {
@@ -153,25 +153,42 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
 #pragma unroll
         for (uint32_t i = 0; i < kP2Own; i++) gm[i] = 0;
         if (entry != kNone && entry < wend) { // (uniform) the path has nodes in this window
-            // A1. successors of all has-positions of the window
+            // A1. successors of all has-positions of the window.  A lane's game reads the records of the positions right behind
+            // its own: those are its neighbours' records (lanes = consecutive positions), fetched with lane shuffles; the first
+            // kP2Over positions behind the wave's 64 are loaded by lanes 0..kP2Over-1 as well.  (A dependent global load per step of
+            // the game -- some lane of the wave always needs one -- was 45% of this kernel.)
 #pragma unroll
             for (uint32_t ib = 0; ib < kP2Own; ib += kP2Pair) {
-                uint2 ra[kP2Pair], rb[kP2Pair];
-                bool hs[kP2Pair];
+                uint2 ra[kP2Pair], rx[kP2Pair];
 #pragma unroll
                 for (uint32_t u = 0; u < kP2Pair; u++) {
-                    const uint32_t p = w0 + (ib + u) * kP2Threads + tid;
-                    hs[u] = p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u);
-                    ra[u] = rb[u] = make_uint2(0, 0);
-                    if (hs[u]) { ra[u] = cx.rec[p]; rb[u] = cx.rec[p + 1]; }
+                    const uint32_t p = w0 + (ib + u) * kP2Threads + tid, px = p + 64; // the overhang: positions 64.. behind the wave's first, one per low lane
+                    ra[u] = p < n ? cx.rec[p] : make_uint2(0, 0);
+                    rx[u] = (lane < kP2Over && px < n) ? cx.rec[px] : make_uint2(0, 0);
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kP2Pair; u++) {
                     const uint32_t x = (ib + u) * kP2Threads + tid, p = w0 + x;
+                    const bool hs = p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u);
+                    uint32_t L = kMinMatch - 1, D = 0, j = 1; // the match in hand starts at p + j - 1
+                    if (hs) L = cx.take(p, kMinMatch - 1, ra[u], D);
+                    bool live = hs;
+                    while (__builtin_amdgcn_ballot_w64(live)) { // all lanes shuffle, the ones in a game use the result
+                        const uint32_t sl = lane + j;
+                        uint2 rn;
+                        const uint32_t ax = (uint32_t)__shfl((int)ra[u].x, (int)(sl & 63u)), ay = (uint32_t)__shfl((int)ra[u].y, (int)(sl & 63u));
+                        const uint32_t bx = (uint32_t)__shfl((int)rx[u].x, (int)(sl & 63u)), by = (uint32_t)__shfl((int)rx[u].y, (int)(sl & 63u));
+                        rn.x = sl < 64 ? ax : bx; rn.y = sl < 64 ? ay : by;
+                        if (live) {
+                            if (sl >= 64 + kP2Over) rn = cx.rec[p + j]; // a game that long is rare
+                            uint32_t D2 = 0;
+                            const uint32_t L2 = cx.take(p + j, L, rn, D2);
+                            if (L2 <= L) live = false; else { L = L2; D = D2; j++; }
+                        }
+                    }
                     uint32_t succ = 0xffffu;
-                    if (hs[u]) {
-                        uint32_t m, L, D;
-                        cx.game(p, ra[u], rb[u], m, L, D);
+                    if (hs) {
+                        const uint32_t m = p + j - 1;
                         gm[ib + u] = ((m - p) << 24) | (L << 15) | D;
                         const uint32_t t = next_bit(HAS, m + L, nwords);
                         if (t < wend) succ = t - w0;
@@ -204,36 +221,89 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
                 EXITS[lane] = x; // where the block's walk leaves the block (kNone: leaves the window)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // other lanes' VIS and EXITS (LDS, same wave: in order)
                 __builtin_amdgcn_wave_barrier();
-                uint32_t cur = entry, last = entry, met_blk = kNone; // wave-uniform
-                while (cur != kNone) {
-                    const uint32_t blk = (cur - w0) / kP2Blk, be2 = w0 + (blk + 1) * kP2Blk;
-                    uint32_t x2 = cur;
-                    met_blk = kNone;
-                    while (x2 != kNone && x2 < be2 && !((VIS[(x2 - w0) >> 5] >> (x2 & 31u)) & 1u)) {
-                        last = x2;
-                        if (lane == 0) atomicOr(&MARK[x2 >> 5], 1u << (x2 & 31u));
+                // Threading, optimistic form: assume the path meets every block's speculative walk inside the block.  Then the blocks
+                // it visits follow from the exits alone (a walk over at most 64 lanes' registers), every visited block finds its
+                // meeting point on its own lane, and the assumption is checked block by block.
+                uint32_t last = entry;
+                bool ok;
+                {
+                    const uint32_t myexit = x;
+                    uint32_t myentry = kNone;              // where the path enters this lane's block
+                    uint32_t cb = (entry - w0) / kP2Blk, ce = entry, lastb = cb;
+                    for (;;) {                             // wave-uniform, no memory
+                        if (lane == cb) myentry = ce;
+                        lastb = cb;
+                        ce = (uint32_t)__builtin_amdgcn_readlane((int)myexit, (int)cb);
+                        if (ce == kNone) break;
+                        cb = (ce - w0) / kP2Blk;
+                    }
+                    // each visited block: from its entry to the meeting point
+                    uint32_t m8[kP2Blk / 32];
+#pragma unroll
+                    for (uint32_t j = 0; j < kP2Blk / 32; j++) m8[j] = 0;
+                    uint32_t x2 = myentry;
+                    bool met = false;
+                    while (x2 != kNone && x2 < be) {
+                        const uint32_t wi = (x2 - bs) >> 5, bit = 1u << (x2 & 31u);
+                        uint32_t vw = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < kP2Blk / 32; j++) vw = wi == j ? v8[j] : vw;
+                        if (vw & bit) { // met: the rest of the speculative walk is the path
+#pragma unroll
+                            for (uint32_t j = 0; j < kP2Blk / 32; j++) m8[j] |= j > wi ? v8[j] : j == wi ? v8[j] & (~0u << (x2 & 31u)) : 0u;
+                            met = true;
+                            break;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < kP2Blk / 32; j++) m8[j] |= wi == j ? bit : 0u;
                         const uint32_t a2 = J[x2 - w0];
                         x2 = a2 == 0xffffu ? kNone : w0 + a2;
                     }
-                    if (x2 != kNone && x2 < be2) { // met at x2
-                        const uint32_t cw = (x2 - w0) >> 5;
-                        if (lane < kP2Blk / 32) {
-                            const uint32_t wd = blk * (kP2Blk / 32) + lane;
-                            uint32_t v = VIS[wd];
-                            if (wd < cw) v = 0; else if (wd == cw) v &= ~0u << (x2 & 31u);
-                            if (v) atomicOr(&MARK[(w0 >> 5) + wd], v);
-                        }
-                        met_blk = blk;
-                        x2 = EXITS[blk];
+                    // a block the path ran through without meeting the walk must at least leave it where the walk does
+                    const bool bad = myentry != kNone && !met && x2 != myexit;
+                    ok = __builtin_amdgcn_ballot_w64(bad) == 0;
+                    if (ok) {
+#pragma unroll
+                        for (uint32_t j = 0; j < kP2Blk / 32; j++) if (m8[j]) atomicOr(&MARK[(w0 >> 5) + lane * (kP2Blk / 32) + j], m8[j]);
+                        uint32_t hi = 0; // 1 + the last path node of this block (window-relative)
+#pragma unroll
+                        for (uint32_t j = 0; j < kP2Blk / 32; j++) if (m8[j]) hi = ((lane * (kP2Blk / 32) + j) << 5) + 32u - (uint32_t)__builtin_clz(m8[j]);
+                        last = w0 + (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)lastb) - 1;
                     }
-                    cur = (uint32_t)__builtin_amdgcn_readfirstlane(x2);
-                    last = (uint32_t)__builtin_amdgcn_readfirstlane(last);
-                    met_blk = (uint32_t)__builtin_amdgcn_readfirstlane(met_blk);
                 }
-                if (met_blk != kNone) { // the path ended inside a speculative walk: its last node is that block's last visited one
-                    uint32_t hi = 0;
-                    for (uint32_t j = 0; j < kP2Blk / 32; j++) { const uint32_t v = VIS[met_blk * (kP2Blk / 32) + j]; if (v) hi = ((met_blk * (kP2Blk / 32) + j) << 5) + 32u - (uint32_t)__builtin_clz(v); }
-                    last = w0 + hi - 1;
+                if (!ok) { // (rare) thread the path block by block, walking until it meets the block's speculative walk
+                    uint32_t cur = entry, met_blk = kNone; // wave-uniform
+                    last = entry;
+                    while (cur != kNone) {
+                        const uint32_t blk = (cur - w0) / kP2Blk, be2 = w0 + (blk + 1) * kP2Blk;
+                        uint32_t x2 = cur;
+                        met_blk = kNone;
+                        while (x2 != kNone && x2 < be2 && !((VIS[(x2 - w0) >> 5] >> (x2 & 31u)) & 1u)) {
+                            last = x2;
+                            if (lane == 0) atomicOr(&MARK[x2 >> 5], 1u << (x2 & 31u));
+                            const uint32_t a2 = J[x2 - w0];
+                            x2 = a2 == 0xffffu ? kNone : w0 + a2;
+                        }
+                        if (x2 != kNone && x2 < be2) { // met at x2
+                            const uint32_t cw = (x2 - w0) >> 5;
+                            if (lane < kP2Blk / 32) {
+                                const uint32_t wd = blk * (kP2Blk / 32) + lane;
+                                uint32_t v = VIS[wd];
+                                if (wd < cw) v = 0; else if (wd == cw) v &= ~0u << (x2 & 31u);
+                                if (v) atomicOr(&MARK[(w0 >> 5) + wd], v);
+                            }
+                            met_blk = blk;
+                            x2 = EXITS[blk];
+                        }
+                        cur = (uint32_t)__builtin_amdgcn_readfirstlane(x2);
+                        last = (uint32_t)__builtin_amdgcn_readfirstlane(last);
+                        met_blk = (uint32_t)__builtin_amdgcn_readfirstlane(met_blk);
+                    }
+                    if (met_blk != kNone) { // the path ended inside a speculative walk: its last node is that block's last visited one
+                        uint32_t hi = 0;
+                        for (uint32_t j = 0; j < kP2Blk / 32; j++) { const uint32_t v = VIS[met_blk * (kP2Blk / 32) + j]; if (v) hi = ((met_blk * (kP2Blk / 32) + j) << 5) + 32u - (uint32_t)__builtin_clz(v); }
+                        last = w0 + hi - 1;
+                    }
                 }
                 if (lane == 0) { // the last path node of the window leads to the entry of the next one
                     uint32_t m, L, D;
