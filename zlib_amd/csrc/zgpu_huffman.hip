@@ -26,14 +26,19 @@ namespace zgpu {
 #endif
 constexpr int kThreads = ZGPU_HUFF_THREADS;
 
+// Heap entries are packed: frequency << 16 | depth << 10 | node.  The reference orders nodes by (frequency, depth) with
+// "<=" deciding ties (smaller(), trees.c:451-453), which on packed entries is one comparison of entry >> 10 -- and a
+// sift-down step needs one 8-byte LDS read (both children) instead of two dependent rounds of 2-byte reads.
+// Ranges: a block holds at most 16384 symbols, so frequencies fit 15 bits; the depth of a Huffman tree over that total
+// weight is at most 21 (Fibonacci bound), 6 bits; nodes are numbered below 2*286+1, 10 bits.
 struct TreeWork {
     uint16_t freq[kHeapSize];
     uint16_t dad[kHeapSize];
     uint16_t len[kHeapSize];
-    uint16_t heap[kHeapSize];
-    uint8_t depth[kHeapSize + 3];
+    __attribute__((aligned(8))) uint32_t heap[kHeapSize + 1]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order
     uint16_t bl_count[kMaxBits + 1];
 };
+__device__ inline uint32_t heap_entry(uint32_t freq, uint32_t depth, uint32_t node) { return (freq << 16) | (depth << 10) | node; }
 
 // LSB-first bit writer into a zero-initialised word buffer.
 struct BitWriter {
@@ -61,20 +66,18 @@ struct BitWriter {
     __device__ void finish() { if (nacc) atomicOr(&words[wi], (uint32_t)acc); nacc = 0; acc = 0; }
 };
 
-__device__ inline bool lighter(const TreeWork &t, int a, int b)
+__device__ inline void sift_down(TreeWork &t, int heap_len, int k) // pqdownheap, trees.c:461-478
 {
-    return t.freq[a] < t.freq[b] || (t.freq[a] == t.freq[b] && t.depth[a] <= t.depth[b]);
-}
-
-__device__ inline void sift_down(TreeWork &t, int heap_len, int k)
-{
-    int v = t.heap[k], j = k << 1;
+    const uint32_t v = t.heap[k];
+    int j = k << 1;
     while (j <= heap_len) {
-        if (j < heap_len && lighter(t, t.heap[j + 1], t.heap[j])) j++;
-        if (lighter(t, v, t.heap[j])) break;
-        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+        const uint2 ch = *reinterpret_cast<const uint2 *>(&t.heap[j]); // children j and j+1 (j is even); j+1 may lie past the heap
+        uint32_t c = ch.x;
+        if (j < heap_len && (ch.y >> 10) <= (ch.x >> 10)) { c = ch.y; j++; }
+        if ((v >> 10) <= (c >> 10)) break;
+        t.heap[k] = c; k = j; j <<= 1;
     }
-    t.heap[k] = (uint16_t)v;
+    t.heap[k] = v;
 }
 
 // build_tree + gen_bitlen + gen_codes, executed by one lane.  t.freq[0..elems) holds the symbol counts.
@@ -86,26 +89,30 @@ __device__ int build_tree(TreeWork &t, int elems, const uint8_t *slen, const uin
 {
     int heap_len = 0, heap_max = kHeapSize, max_code = -1, n, m, node;
     for (n = 0; n < elems; n++) {
-        if (t.freq[n] != 0) { t.heap[++heap_len] = (uint16_t)(max_code = n); t.depth[n] = 0; }
+        if (t.freq[n] != 0) t.heap[++heap_len] = heap_entry(t.freq[n], 0, (uint32_t)(max_code = n));
         else t.len[n] = 0;
     }
     while (heap_len < 2) {
-        node = t.heap[++heap_len] = (uint16_t)(max_code < 2 ? ++max_code : 0);
-        t.freq[node] = 1; t.depth[node] = 0; opt_len--;
+        node = max_code < 2 ? ++max_code : 0;
+        t.heap[++heap_len] = heap_entry(1, 0, (uint32_t)node);
+        t.freq[node] = 1; opt_len--;
         if (slen) static_len -= slen[node];
     }
     for (n = heap_len / 2; n >= 1; n--) sift_down(t, heap_len, n);
     node = elems;
     do {
-        n = t.heap[1]; t.heap[1] = t.heap[heap_len--]; sift_down(t, heap_len, 1);
-        m = t.heap[1];
-        t.heap[--heap_max] = (uint16_t)n; t.heap[--heap_max] = (uint16_t)m;
-        t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
-        t.depth[node] = (uint8_t)((t.depth[n] >= t.depth[m] ? t.depth[n] : t.depth[m]) + 1);
+        const uint32_t en = t.heap[1];
+        t.heap[1] = t.heap[heap_len--]; sift_down(t, heap_len, 1);
+        const uint32_t em = t.heap[1];
+        n = (int)(en & 1023u); m = (int)(em & 1023u);
+        t.heap[--heap_max] = (uint32_t)n; t.heap[--heap_max] = (uint32_t)m;
+        const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
         t.dad[n] = t.dad[m] = (uint16_t)node;
-        t.heap[1] = (uint16_t)node++; sift_down(t, heap_len, 1);
+        t.heap[1] = heap_entry((en >> 16) + (em >> 16), (dn >= dm ? dn : dm) + 1, (uint32_t)node);
+        node++;
+        sift_down(t, heap_len, 1);
     } while (heap_len >= 2);
-    t.heap[--heap_max] = t.heap[1];
+    t.heap[--heap_max] = t.heap[1] & 1023u;
 
     // gen_bitlen
     int h, bits, overflow = 0;
