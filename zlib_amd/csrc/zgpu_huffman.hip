@@ -31,13 +31,17 @@ constexpr int kThreads = ZGPU_HUFF_THREADS;
 // sift-down step needs one 8-byte LDS read (both children) instead of two dependent rounds of 2-byte reads.
 // Ranges: a block holds at most 16384 symbols, so frequencies fit 15 bits; the depth of a Huffman tree over that total
 // weight is at most 21 (Fibonacci bound), 6 bits; nodes are numbered below 2*286+1, 10 bits.
-struct TreeWork {
-    uint16_t freq[kHeapSize];
-    uint16_t dad[kHeapSize];
-    uint16_t len[kHeapSize];
-    __attribute__((aligned(8))) uint32_t heap[kHeapSize + 1]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order
+template <int kNodes> // 2 * symbols + 1 (HEAP_SIZE of the tree in question)
+struct TreeWorkT {
+    static constexpr int kCap = kNodes;
+    uint16_t freq[kNodes];
+    uint16_t dad[kNodes];
+    uint16_t len[kNodes];
+    __attribute__((aligned(8))) uint32_t heap[kNodes + 1]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order
     uint16_t bl_count[kMaxBits + 1];
 };
+using TreeWork = TreeWorkT<kHeapSize>;          // literal/length tree, and the bit-length tree after it
+using TreeWorkD = TreeWorkT<2 * kDCodes + 1>;    // distance tree: a tenth of the LDS, so more chunks are resident per CU
 __device__ inline uint32_t heap_entry(uint32_t freq, uint32_t depth, uint32_t node) { return (freq << 16) | (depth << 10) | node; }
 
 // LSB-first bit writer into a zero-initialised word buffer.
@@ -66,7 +70,8 @@ struct BitWriter {
     __device__ void finish() { if (nacc) atomicOr(&words[wi], (uint32_t)acc); nacc = 0; acc = 0; }
 };
 
-__device__ inline void sift_down(TreeWork &t, int heap_len, int k) // pqdownheap, trees.c:461-478
+template <class TW>
+__device__ inline void sift_down(TW &t, int heap_len, int k) // pqdownheap, trees.c:461-478
 {
     const uint32_t v = t.heap[k];
     int j = k << 1;
@@ -84,10 +89,11 @@ __device__ inline void sift_down(TreeWork &t, int heap_len, int k) // pqdownheap
 // slen: static code lengths (constant memory) or nullptr; xbits/xbase: extra-bit table and first symbol using it.
 // Results: out_len / out_code for symbols 0..elems-1; returns max_code.  opt_len / static_len accumulate mod 2^32
 // exactly like the reference's unsigned long arithmetic does mod 2^64 (the transient "-1" of the forced codes).
-__device__ int build_tree(TreeWork &t, int elems, const uint8_t *slen, const uint8_t *xbits, int xbase, int max_length,
+template <class TW>
+__device__ int build_tree(TW &t, int elems, const uint8_t *slen, const uint8_t *xbits, int xbase, int max_length,
                           uint16_t *out_code, uint8_t *out_len, uint32_t &opt_len, uint32_t &static_len)
 {
-    int heap_len = 0, heap_max = kHeapSize, max_code = -1, n, m, node;
+    int heap_len = 0, heap_max = TW::kCap, max_code = -1, n, m, node;
     for (n = 0; n < elems; n++) {
         if (t.freq[n] != 0) t.heap[++heap_len] = heap_entry(t.freq[n], 0, (uint32_t)(max_code = n));
         else t.len[n] = 0;
@@ -118,7 +124,7 @@ __device__ int build_tree(TreeWork &t, int elems, const uint8_t *slen, const uin
     int h, bits, overflow = 0;
     for (bits = 0; bits <= kMaxBits; bits++) t.bl_count[bits] = 0;
     t.len[t.heap[heap_max]] = 0;
-    for (h = heap_max + 1; h < kHeapSize; h++) {
+    for (h = heap_max + 1; h < TW::kCap; h++) {
         n = t.heap[h]; bits = t.len[t.dad[n]] + 1;
         if (bits > max_length) { bits = max_length; overflow++; }
         t.len[n] = (uint16_t)bits;
@@ -229,9 +235,10 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     return base + x - v;
 }
 
-__global__ void __launch_bounds__(kThreads) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots)
+__global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots)
 {
-    __shared__ TreeWork work[2];
+    __shared__ TreeWork work0;
+    __shared__ TreeWorkD work1;
     __shared__ uint32_t hist[kLCodes + kDCodes + 2];
     __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
     __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
@@ -274,25 +281,25 @@ __global__ void __launch_bounds__(kThreads) huffman_kernel(ChunkGeom g, const ui
             if (tid < 32 && (tid < 9 || tid >= 14)) bin = hist[tid] != 0;
             data_type = __syncthreads_or(bin) ? 0u : 1u;
         }
-        for (uint32_t i = tid; i < kLCodes; i += kThreads) work[0].freq[i] = (uint16_t)hist[i];
-        if (tid < kDCodes) work[1].freq[tid] = (uint16_t)hist[kLCodes + tid];
+        for (uint32_t i = tid; i < kLCodes; i += kThreads) work0.freq[i] = (uint16_t)hist[i];
+        if (tid < kDCodes) work1.freq[tid] = (uint16_t)hist[kLCodes + tid];
         __syncthreads();
         // ---- trees ----
         if (tid == 0) {
             uint32_t o = 0, s = 0;
-            sh_lmax = (uint32_t)build_tree(work[0], kLCodes, kTables.sl_len, kTables.xl, 257, kMaxBits, lcode, llen, o, s);
+            sh_lmax = (uint32_t)build_tree(work0, kLCodes, kTables.sl_len, kTables.xl, 257, kMaxBits, lcode, llen, o, s);
             sh_optl = o; sh_statl = s;
         } else if (tid == 64) {
             for (int i = 0; i < kDCodes; i++) five[i] = 5;
             uint32_t o = 0, s = 0;
-            sh_dmax = (uint32_t)build_tree(work[1], kDCodes, five, kTables.xd, 0, kMaxBits, dcode, dlen, o, s);
+            sh_dmax = (uint32_t)build_tree(work1, kDCodes, five, kTables.xd, 0, kMaxBits, dcode, dlen, o, s);
             sh_optd = o; sh_statd = s;
         }
         __syncthreads();
         if (tid == 0) {
             uint32_t opt_len = sh_optl + sh_optd, static_len = sh_statl + sh_statd;
             const int lmax = (int)sh_lmax, dmax = (int)sh_dmax;
-            TreeWork &w = work[0];
+            TreeWork &w = work0;
             for (int i = 0; i < kBLCodes; i++) w.freq[i] = 0;
             walk_lengths(llen, lmax, w.freq, nullptr, nullptr, nullptr);
             walk_lengths(dlen, dmax, w.freq, nullptr, nullptr, nullptr);
