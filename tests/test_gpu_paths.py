@@ -1,0 +1,62 @@
+"""GPU: the alternative kernel paths of the levels 4-9 pipeline must produce the same bytes as the default one.
+
+  ZGPU_SORT=1            sort_kernel (ballots only) instead of sort3_kernel (ordered LDS atomics + self-check)
+  ZGPU_SORT_FAULT_TEST=1 sort3's self-check reports a fault -> the engine redoes the call with sort_kernel
+  ZGPU_PARSE=1           parse_kernel (the reference loop, one lane per chunk) instead of parse2_kernel
+
+The switches are read once per process, so every variant runs in a child process (one at a time) and prints the
+SHA-256 of its streams; the default variant's digests are additionally pinned to the oracle in this process."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+from oracle import cases, corpus_py as CP
+import zlib_amd
+e = zlib_amd.Engine(0)
+out = {}
+inputs = {
+    "corpus0": CP.chunks(0, 0, 24).tobytes(),
+    "corpus1": CP.chunks(1, 3, 8).tobytes(),
+    "hello": cases.hello_1mib()[: 5 * 65536 + 77],
+    "zeros": bytes(3 * 65536 + 5),
+    "ragged": CP.chunks(0, 40, 2).tobytes()[: 65536 + 2],
+}
+for name, data in inputs.items():
+    for lvl in (4, 6, 9):
+        out["%%s/%%d" %% (name, lvl)] = hashlib.sha256(e.deflate_host(data, lvl)).hexdigest()
+print("DIGESTS " + json.dumps(out, sort_keys=True))
+""" % ROOT
+
+
+def run_variant(env_extra):
+    env = dict(os.environ)
+    for k in ("ZGPU_SORT", "ZGPU_SORT_FAULT_TEST", "ZGPU_PARSE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("DIGESTS ")][-1]
+    return json.loads(line[len("DIGESTS "):])
+
+
+def test_alternative_paths_agree():
+    base = run_variant({})
+    # pin the default path to the oracle for two of the inputs (the rest of the suite does this at length)
+    from oracle import corpus_py as CP, oracle_py as O
+    data = CP.chunks(0, 0, 24).tobytes()
+    assert base["corpus0/6"] == hashlib.sha256(O.deflate_stream(data, 6, 65536)).hexdigest()
+    assert base["zeros/9"] == hashlib.sha256(O.deflate_stream(bytes(3 * 65536 + 5), 9, 65536)).hexdigest()
+    for env in ({"ZGPU_SORT": "1"}, {"ZGPU_SORT_FAULT_TEST": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}):
+        got = run_variant(env)
+        assert got == base, "variant %r differs: %s" % (env, [k for k in base if got.get(k) != base[k]])
