@@ -41,20 +41,25 @@ static const char *const kInfMessages[kMsgCount] = {
 
 struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t pad; };
 
-constexpr uint32_t kLBits = 10, kDBits = 9, kStageDwords = 512;
+constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 512;
+constexpr uint32_t kOutRing = 32768, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
+
+// Decoding table entries of the literal/length and distance codes carry everything the symbol loop needs:
+//   bits 0-3 code length, 4-7 extra bits, 8 literal, 9 end of block, 10 length/distance, 11 invalid symbol, 16-31 byte / base value
+constexpr uint32_t kEntLit = 1u << 8, kEntEob = 1u << 9, kEntLen = 1u << 10, kEntBad = 1u << 11;
 
 struct InflateLds {
-    uint8_t out[kChunkMax];
-    uint32_t ltab[1 << kLBits]; // sym << 8 | len, 0 = longer than kLBits (or unassigned)
+    uint8_t out[kOutRing];
+    uint32_t ltab[1 << kLBits]; // 0 = code longer than kLBits (or unassigned)
     uint32_t dtab[1 << kDBits];
     uint32_t stage[kStageDwords]; // ring of input dwords
     uint16_t lens[320];
     uint16_t lsym[288], dsym[32]; // symbols sorted by (length, symbol) for the long-code walk
     uint16_t lcount[16], dcount[16];
-    uint16_t code_of[320]; // canonical code of each symbol while a table is being built
-    uint16_t work_offs[16], work_next[16];
-    uint32_t build_rc;
+    uint16_t work_offs[16], work_first[16], work_start[16];
+    uint32_t build_rc, build_n;
 };
+static_assert(sizeof(InflateLds) <= 40448, "four waves per CU");
 
 // Wave-uniform bit reader over a ring of input dwords in LDS.
 struct BitSrc {
@@ -93,15 +98,35 @@ __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b
 // Build one decoding table from code lengths lens[0..n).  kind: 0 code-length code, 1 literal/length, 2 distance.
 // Acceptance rules of inflate_table (inftrees.c:106-138).  Returns 0 ok, 1 rejected.  Lane 0 does the serial part
 // (its small work arrays live in LDS: dynamically indexed private arrays would go to scratch memory).
+__constant__ const uint16_t kLBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ const uint8_t kLExt[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ const uint16_t kDBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ const uint8_t kDExt[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// table entry of symbol s with code length l.  kind: 0 code-length code (plain sym << 8 | len), 1 literal/length, 2 distance
+__device__ inline uint32_t make_entry(uint32_t kind, uint32_t s, uint32_t l)
+{
+    if (kind == 0) return (s << 8) | l;
+    if (kind == 1) {
+        if (s < 256) return l | kEntLit | (s << 16);
+        if (s == 256) return l | kEntEob;
+        if (s > 285) return l | kEntBad;
+        return l | ((uint32_t)kLExt[s - 257] << 4) | kEntLen | ((uint32_t)kLBase[s - 257] << 16);
+    }
+    if (s > 29) return l | kEntBad;
+    return l | ((uint32_t)kDExt[s] << 4) | kEntLen | ((uint32_t)kDBase[s] << 16);
+}
+
 __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
                                              uint16_t *sorted, uint16_t *count, uint32_t lane)
 {
     __syncthreads();
     for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
     if (lane == 0) {
-        uint16_t *cnt = count, *offs = L.work_offs, *next = L.work_next;
+        uint16_t *cnt = count, *offs = L.work_offs, *first = L.work_first, *start = L.work_start;
         for (int l = 0; l < 16; l++) cnt[l] = 0;
-        for (uint32_t s = 0; s < n; s++) cnt[lens[s]]++;
+        for (uint32_t s2 = 0; s2 < n; s2++) cnt[lens[s2]]++;
         int maxl = 15; while (maxl >= 1 && cnt[maxl] == 0) maxl--;
         uint32_t rc = 0;
         if (maxl > 0) {
@@ -110,18 +135,21 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
             if (!rc && left > 0 && (kind == 0 || maxl != 1)) rc = 1; // incomplete set
         }
         uint32_t c = 0; offs[1] = 0; cnt[0] = 0;
-        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; next[l] = (uint16_t)c; if (l < 15) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); }
-        if (!rc) for (uint32_t s = 0; s < n; s++) { const uint32_t l = lens[s]; if (l) { L.code_of[s] = next[l]++; sorted[offs[l]++] = (uint16_t)s; } }
+        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; first[l] = (uint16_t)c; if (l < 15) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); }
+        for (int l = 1; l <= 15; l++) start[l] = offs[l];
+        L.build_n = (uint32_t)offs[15] + cnt[15];
+        if (!rc) for (uint32_t s2 = 0; s2 < n; s2++) { const uint32_t l = lens[s2]; if (l) sorted[offs[l]++] = (uint16_t)s2; }
         L.build_rc = rc;
     }
     __syncthreads();
     const uint32_t rc = L.build_rc;
     if (rc == 0) {
-        for (uint32_t s = lane; s < n; s += 64) {
-            const uint32_t l = lens[s];
-            if (l && l <= tbits) {
-                const uint32_t rev = __brev((uint32_t)L.code_of[s]) >> (32 - l);
-                for (uint32_t i = rev; i < (1u << tbits); i += 1u << l) tab[i] = (s << 8) | l;
+        // symbol number j in (length, symbol) order has the canonical code first[l] + (j - start[l])
+        for (uint32_t j = lane; j < L.build_n; j += 64) {
+            const uint32_t s2 = sorted[j], l = lens[s2];
+            if (l <= tbits) {
+                const uint32_t code = (uint32_t)L.work_first[l] + (j - L.work_start[l]), rev = __brev(code) >> (32 - l), e = make_entry(kind, s2, l);
+                for (uint32_t i = rev; i < (1u << tbits); i += 1u << l) tab[i] = e;
             }
         }
     }
@@ -146,11 +174,19 @@ __device__ __noinline__ uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint
     return 0xFFFFu;
 }
 
-__constant__ const uint16_t kLBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ const uint8_t kLExt[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ const uint16_t kDBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ const uint8_t kDExt[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__constant__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// canonical walk (first-code method) over the bits in b.hold: the symbol of a code of any length, 0xFFFF if unassigned
+__device__ __noinline__ uint32_t decode_long(BitSrc &b, const uint16_t *sorted, const uint16_t *count)
+{
+    int code = 0, first = 0, index = 0;
+    uint64_t h = b.hold;
+    for (uint32_t l = 1; l <= 15; l++) {
+        code |= (int)(h & 1); h >>= 1;
+        const int c = count[l];
+        if (code - c < first) { drop(b, l); return sorted[index + (code - first)]; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return 0xFFFFu;
+}
 
 __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
                                                      uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
@@ -182,7 +218,26 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     refill(b, L.stage); refill(b, L.stage);
     drop(b, lead * 8);
 
-    uint32_t o = 0; // bytes produced
+    uint32_t o = 0;       // bytes produced
+    uint32_t flushed = 0; // bytes already copied from the LDS ring to the destination (a multiple of kOutHalf until the end)
+    bool nofit = false;   // direct placement: the destination ended before the chunk did
+    uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
+    const uint64_t dst_room = compact ? kChunkMax : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
+    // copy bytes [flushed, upto) of the output to the destination; the range never wraps in the ring
+    auto flush_to = [&](uint32_t upto) {
+        uint32_t nbytes = upto - flushed;
+        if ((uint64_t)flushed + nbytes > dst_room) { nofit = true; nbytes = dst_room > flushed ? (uint32_t)(dst_room - flushed) : 0; }
+        const uint8_t *src_r = L.out + (flushed & (kOutRing - 1));
+        uint8_t *d = dst + flushed;
+        if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+            const uint4 *s128 = reinterpret_cast<const uint4 *>(src_r);
+            for (uint32_t i = lane; i < (nbytes >> 4); i += 64) reinterpret_cast<uint4 *>(d)[i] = s128[i];
+            for (uint32_t i = (nbytes & ~15u) + lane; i < nbytes; i += 64) d[i] = src_r[i];
+        } else {
+            for (uint32_t i = lane; i < nbytes; i += 64) d[i] = src_r[i];
+        }
+        flushed = upto;
+    };
     bool last = false, seen_final = false;
     while (!err && !last) {
         if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
@@ -203,8 +258,13 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             if ((uint64_t)bytepos + len > (b.seg_bits >> 3)) { err = kMsgTruncated; break; }
             if (o + len > chunk_size) { err = kMsgOutput; break; }
             const uint8_t *src = reinterpret_cast<const uint8_t *>(b.g32 + b.d0) + bytepos;
-            for (uint32_t i = lane; i < len; i += 64) L.out[o + i] = src[i];
-            o += len;
+            for (uint32_t done = 0; done < len;) { // through the ring, half by half
+                const uint32_t room = flushed + kOutHalf - o, part = len - done < room ? len - done : room;
+                for (uint32_t i = lane; i < part; i += 64) L.out[(o + i) & (kOutRing - 1)] = src[done + i];
+                o += part; done += part;
+                __syncthreads();
+                if (o == flushed + kOutHalf) flush_to(o);
+            }
             // reposition the reader right after the stored bytes: new origin = the dword holding that byte
             const uint32_t np = bytepos + len;
             b.d0 += np >> 2; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
@@ -274,41 +334,58 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             stage_fill(b, L.stage, lane);
             refill(b, L.stage);
             if (consumed_bits(b) > b.seg_bits) { err = kMsgTruncated; break; }
-            uint32_t s = decode_sym(b, L.ltab, kLBits, L.lsym, L.lcount);
-            if (s == 0xFFFFu || s > 285) { err = kMsgLitCode; break; }
-            if (s < 256) {
+            uint32_t e = L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)];
+            if (e) drop(b, e & 15u);
+            else { // a code longer than the table, or no code at all
+                const uint32_t s2 = decode_long(b, L.lsym, L.lcount);
+                if (s2 == 0xFFFFu) { err = kMsgLitCode; break; }
+                e = make_entry(1, s2, 0);
+            }
+            if (e & kEntLit) {
                 if (o >= chunk_size) { err = kMsgOutput; break; }
-                if (lane == 0) L.out[o] = (uint8_t)s;
+                L.out[o & (kOutRing - 1)] = (uint8_t)(e >> 16); // (every lane stores the same byte)
                 o++;
+                if (o == flushed + kOutHalf) flush_to(o);
                 continue;
             }
-            if (s == 256) break;
-            s -= 257;
-            const uint32_t len = kLBase[s] + peek(b, kLExt[s]); drop(b, kLExt[s]);
+            if (e & kEntEob) break;
+            if (e & kEntBad) { err = kMsgLitCode; break; }
+            const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
+            drop(b, xl);
             refill(b, L.stage);
-            const uint32_t d = decode_sym(b, L.dtab, kDBits, L.dsym, L.dcount);
-            if (d == 0xFFFFu || d > 29) { err = kMsgDistCode; break; }
-            const uint32_t dist = kDBase[d] + peek(b, kDExt[d]); drop(b, kDExt[d]);
+            uint32_t ed = L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)];
+            if (ed) drop(b, ed & 15u);
+            else {
+                const uint32_t d2 = decode_long(b, L.dsym, L.dcount);
+                if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
+                ed = make_entry(2, d2, 0);
+            }
+            if (ed & kEntBad) { err = kMsgDistCode; break; }
+            const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
+            drop(b, xd);
             if (dist > o) { err = kMsgTooFar; break; }
             if (o + len > chunk_size) { err = kMsgOutput; break; }
-            // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259).
+            // The ring holds the last 32 KiB: a read at the full distance 32768 hits the slot its own lane is about to write.
+            __builtin_amdgcn_wave_barrier();
             if (dist >= len || dist >= 64) {
                 for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
                     const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
                     uint8_t v = 0;
-                    if (lane < span && i < len) v = L.out[o - dist + i];
-                    if (lane < span && i < len) L.out[o + i] = v;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane < span && i < len) v = L.out[(o - dist + i) & (kOutRing - 1)];
+                    if (lane < span && i < len) L.out[(o + i) & (kOutRing - 1)] = v;
+                    __builtin_amdgcn_wave_barrier();
                 }
             } else {
                 const uint32_t recip = 0xFFFFFFFFu / dist + 1;
                 for (uint32_t i = lane; i < len; i += 64) {
                     const uint32_t qd = dist == 1 ? i : __umulhi(i, recip), r = i - qd * dist; // recip overflows for dist 1
-                    L.out[o + i] = L.out[o - dist + r];
+                    L.out[(o + i) & (kOutRing - 1)] = L.out[(o - dist + r) & (kOutRing - 1)];
                 }
+                __builtin_amdgcn_wave_barrier();
             }
             o += len;
+            if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
         }
     }
     // an error found in bits that lie past the end of the segment is the zero padding talking: the segment is truncated
@@ -325,18 +402,9 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
 #endif
     __syncthreads();
-    // store the chunk
-    uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
-    const bool fits = compact || gc * (uint64_t)chunk_size + o <= out_cap;
-    if (!err && fits) {
-        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-            const uint4 *s128 = reinterpret_cast<const uint4 *>(L.out);
-            for (uint32_t i = lane; i < (o >> 4); i += 64) reinterpret_cast<uint4 *>(dst)[i] = s128[i];
-            for (uint32_t i = (o & ~15u) + lane; i < o; i += 64) dst[i] = L.out[i];
-        } else {
-            for (uint32_t i = lane; i < o; i += 64) dst[i] = L.out[i];
-        }
-    }
+    // the rest of the chunk (an error leaves what was flushed before it was found; the status says the chunk is void)
+    if (!err) flush_to(o);
+    const bool fits = !nofit;
     if (lane == 0) {
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
