@@ -70,8 +70,13 @@ struct BitSrc {
     uint32_t rd;         // dwords consumed into hold
     uint64_t hold;
     uint32_t bits;
+    uint32_t nx;         // stage[rd]: read one refill ahead so that a refill never waits for LDS
     uint32_t seg_bits;   // size of the segment in bits (from its first dword, including the leading byte offset)
 };
+
+// The bit reader's state is the same in all lanes; values that come back from LDS are declared so (v_readfirstlane), which
+// moves the whole decode loop -- shifts, masks, compares, branches -- from the vector pipe to scalar instructions.
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
 {
@@ -89,8 +94,9 @@ __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
 }
 __device__ inline void refill(BitSrc &b, const uint32_t *stage)
 {
-    if (b.bits <= 32) { b.hold |= (uint64_t)stage[b.rd & (kStageDwords - 1)] << b.bits; b.rd++; b.bits += 32; }
+    if (b.bits <= 32) { b.hold |= (uint64_t)uni(b.nx) << b.bits; b.rd++; b.bits += 32; b.nx = stage[b.rd & (kStageDwords - 1)]; } // nx stays a vector register: the wait for it belongs to its use
 }
+__device__ inline void prime(BitSrc &b, const uint32_t *stage) { b.nx = stage[b.rd & (kStageDwords - 1)]; } // after (re)positioning the reader
 __device__ inline uint32_t peek(const BitSrc &b, uint32_t n) { return (uint32_t)b.hold & ((1u << n) - 1); }
 __device__ inline void drop(BitSrc &b, uint32_t n) { b.hold >>= n; b.bits -= n; }
 __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b.bits; }
@@ -158,34 +164,30 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
 }
 
 // decode one symbol; returns the symbol, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code)
-__device__ __noinline__ uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
+// canonical walk (first-code method) over the low bits of `hold`: symbol | code length << 16 of a code of any length,
+// 0xFFFF if the pattern is not assigned.  Takes the bits by value: a reader passed by reference to a real call lives in
+// scratch memory, and every access of the decode loop to its own state then costs a trip to HBM.
+__device__ __noinline__ uint32_t decode_long(uint64_t h, const uint16_t *sorted, const uint16_t *count)
 {
-    const uint32_t e = tab[peek(b, tbits)];
-    if (e) { drop(b, e & 255); return e >> 8; }
-    // canonical walk (first-code method) for codes longer than the table, and for unassigned patterns
     int code = 0, first = 0, index = 0;
-    uint64_t h = b.hold;
     for (uint32_t l = 1; l <= 15; l++) {
         code |= (int)(h & 1); h >>= 1;
         const int c = count[l];
-        if (code - c < first) { drop(b, l); return sorted[index + (code - first)]; }
+        if (code - c < first) return (uint32_t)sorted[index + (code - first)] | (l << 16);
         index += c; first += c; first <<= 1; code <<= 1;
     }
     return 0xFFFFu;
 }
 
-// canonical walk (first-code method) over the bits in b.hold: the symbol of a code of any length, 0xFFFF if unassigned
-__device__ __noinline__ uint32_t decode_long(BitSrc &b, const uint16_t *sorted, const uint16_t *count)
+// decode one symbol of the code-length code (plain entries sym << 8 | len); 0xFFFF when the bit pattern is not assigned
+__device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
 {
-    int code = 0, first = 0, index = 0;
-    uint64_t h = b.hold;
-    for (uint32_t l = 1; l <= 15; l++) {
-        code |= (int)(h & 1); h >>= 1;
-        const int c = count[l];
-        if (code - c < first) { drop(b, l); return sorted[index + (code - first)]; }
-        index += c; first += c; first <<= 1; code <<= 1;
-    }
-    return 0xFFFFu;
+    const uint32_t e = uni(tab[peek(b, tbits)]);
+    if (e) { drop(b, e & 255); return e >> 8; }
+    const uint32_t r = uni(decode_long(b.hold, sorted, count));
+    if (r == 0xFFFFu) return r;
+    drop(b, r >> 16);
+    return r & 0xFFFFu;
 }
 
 __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
@@ -215,6 +217,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     b.seg_bits = (uint32_t)(seg_hi - seg_lo + lead) * 8;
     stage_fill(b, L.stage, lane);
     __syncthreads();
+    prime(b, L.stage);
     refill(b, L.stage); refill(b, L.stage);
     drop(b, lead * 8);
 
@@ -224,7 +227,11 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
     const uint64_t dst_room = compact ? kChunkMax : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
     // copy bytes [flushed, upto) of the output to the destination; the range never wraps in the ring
+    // a match's bytes are loaded when it is decoded and stored while the next symbol's table entry is on its way (commit)
+    uint32_t pend_addr = 0; uint8_t pend_v = 0; bool pend = false;
+    auto commit = [&]() { if (pend) { L.out[pend_addr] = pend_v; pend = false; } };
     auto flush_to = [&](uint32_t upto) {
+        commit();
         uint32_t nbytes = upto - flushed;
         if ((uint64_t)flushed + nbytes > dst_room) { nofit = true; nbytes = dst_room > flushed ? (uint32_t)(dst_room - flushed) : 0; }
         const uint8_t *src_r = L.out + (flushed & (kOutRing - 1));
@@ -240,6 +247,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     };
     bool last = false, seen_final = false;
     while (!err && !last) {
+        commit();
         if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
         stage_fill(b, L.stage, lane); __syncthreads();
         refill(b, L.stage);
@@ -271,6 +279,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             b.seg_bits -= (np & ~3u) * 8; // seg_bits stays relative to the origin
             __syncthreads();
             stage_fill(b, L.stage, lane); __syncthreads();
+            prime(b, L.stage);
             refill(b, L.stage); refill(b, L.stage);
             drop(b, (np & 3) * 8);
             continue;
@@ -334,12 +343,14 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             stage_fill(b, L.stage, lane);
             refill(b, L.stage);
             if (consumed_bits(b) > b.seg_bits) { err = kMsgTruncated; break; }
-            uint32_t e = L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)];
+            uint32_t e = uni(L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)]);
+            commit();
             if (e) drop(b, e & 15u);
             else { // a code longer than the table, or no code at all
-                const uint32_t s2 = decode_long(b, L.lsym, L.lcount);
+                const uint32_t s2 = uni(decode_long(b.hold, L.lsym, L.lcount));
                 if (s2 == 0xFFFFu) { err = kMsgLitCode; break; }
-                e = make_entry(1, s2, 0);
+                drop(b, s2 >> 16);
+                e = make_entry(1, s2 & 0xFFFFu, 0);
             }
             if (e & kEntLit) {
                 if (o >= chunk_size) { err = kMsgOutput; break; }
@@ -353,12 +364,13 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
             drop(b, xl);
             refill(b, L.stage);
-            uint32_t ed = L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)];
+            uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
             if (ed) drop(b, ed & 15u);
             else {
-                const uint32_t d2 = decode_long(b, L.dsym, L.dcount);
+                const uint32_t d2 = uni(decode_long(b.hold, L.dsym, L.dcount));
                 if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
-                ed = make_entry(2, d2, 0);
+                drop(b, d2 >> 16);
+                ed = make_entry(2, d2 & 0xFFFFu, 0);
             }
             if (ed & kEntBad) { err = kMsgDistCode; break; }
             const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
@@ -368,7 +380,9 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259).
             // The ring holds the last 32 KiB: a read at the full distance 32768 hits the slot its own lane is about to write.
             __builtin_amdgcn_wave_barrier();
-            if (dist >= len || dist >= 64) {
+            if (len <= 64 && dist >= len) { // the common case: one load per lane now, the store later
+                if (lane < len) { pend_v = L.out[(o - dist + lane) & (kOutRing - 1)]; pend_addr = (o + lane) & (kOutRing - 1); pend = true; }
+            } else if (dist >= len || dist >= 64) {
                 for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
                     const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
                     uint8_t v = 0;
@@ -401,6 +415,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
 #ifdef ZGPU_INF_DEBUG2
     if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
 #endif
+    commit();
     __syncthreads();
     // the rest of the chunk (an error leaves what was flushed before it was found; the status says the chunk is void)
     if (!err) flush_to(o);
