@@ -78,6 +78,12 @@ struct BitSrc {
 // moves the whole decode loop -- shifts, masks, compares, branches -- from the vector pipe to scalar instructions.
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+__device__ inline void settle(BitSrc &b) // (the compiler cannot see that loop-carried reader state is wave-uniform: tell it once per symbol)
+{
+    b.hold = (uint64_t)uni((uint32_t)b.hold) | ((uint64_t)uni((uint32_t)(b.hold >> 32)) << 32);
+    b.bits = uni(b.bits); b.rd = uni(b.rd); b.filled = uni(b.filled);
+}
+
 __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
 {
     // keep at least 256 dwords ahead of the reader; each call loads 256 dwords (16 bytes per lane)
@@ -340,6 +346,8 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         __syncthreads();
         // ---- symbols ----
         for (;;) {
+            settle(b);
+            o = uni(o); flushed = uni(flushed);
             stage_fill(b, L.stage, lane);
             refill(b, L.stage);
             if (consumed_bits(b) > b.seg_bits) { err = kMsgTruncated; break; }
