@@ -433,7 +433,7 @@ __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32
 // whatever was appended after the stopping candidate loses against its key.  The quarter-budget result (deflate.c:1146)
 // is the slot as it stands once every candidate k < chain/4 has been folded.
 #ifndef ZGPU_M3_PERIOD
-#define ZGPU_M3_PERIOD 32 // steps between forced folds (keeps the walkers' best length fresh); a power of two <= 256
+#define ZGPU_M3_PERIOD 128 // steps between forced folds (keeps the walkers' best length fresh); a power of two <= 256
 #endif
 #ifdef ZGPU_M3_STATS // debug build only (scripts/m3_stats.py): 0 wave-steps, 1 active lane-steps, 2 ring entries, 3 folds, 4 fold iterations, 5 positions
 __device__ unsigned long long m3_stats[8];
