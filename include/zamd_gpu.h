@@ -43,6 +43,9 @@ extern "C" {
 #define ZGPU_F_ZLIB_WRAP 2u /* prepend the 2-byte zlib header, append the big-endian Adler-32 (needs FINAL) */
 #define ZGPU_F_POS0 4u      /* chunks other than the first are "position-0 matchable" (mode A) */
 #define ZGPU_F_POS0_ALL 8u  /* every chunk, including the first, is position-0 matchable */
+#define ZGPU_F_GZIP_WRAP 16u /* gzip member: the 10-byte header deflate() writes without a gz_header (qcsrc/deflate.c:578-596),
+                               the body, CRC-32 and length little-endian (deflate.c:833-843); needs FINAL */
+#define ZGPU_F_CRC32 32u     /* also compute the CRC-32 of the input (result.crc32) without writing a wrapper */
 
 /* LZ77 match-finder implementation selector (debug / A-B measurements) */
 #define ZGPU_LZ_AUTO 0
@@ -65,6 +68,8 @@ typedef struct {
     uint32_t adler32;    /* Adler-32 of the whole input (1 for empty input) */
     uint32_t data_type;  /* Z_BINARY 0 / Z_TEXT 1 / Z_UNKNOWN 2, as strm->data_type after the first block */
     uint64_t ntokens;    /* literal/match tokens over all chunks (diagnostic) */
+    uint32_t crc32;      /* CRC-32 of the whole input when ZGPU_F_GZIP_WRAP or ZGPU_F_CRC32 was given, else 0 */
+    uint32_t reserved;
 } zgpu_deflate_result;
 
 typedef struct {
@@ -73,6 +78,8 @@ typedef struct {
     int32_t first_bad_chunk; /* -1, or the first chunk that failed */
     int32_t error_code;   /* ZGPU_OK or the failure of first_bad_chunk */
     uint32_t error_msg;   /* index into zgpu_inflate_message() */
+    uint32_t crc32;       /* CRC-32 of the produced bytes */
+    uint32_t reserved;
 } zgpu_inflate_result;
 
 /* ---- engine lifetime ---- */
@@ -132,6 +139,8 @@ const char *zgpu_inflate_message(uint32_t index);
 
 /* ---- checksums (qcsrc/adler32.c:57-149) ---- */
 int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream);
+/* CRC-32 as crc32() computes it (qcsrc/crc32.c:219-266), chunk CRCs joined like crc32_combine (crc32.c:370-423) */
+int zgpu_crc32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *crc_out, void *hip_stream);
 
 /* ---- measurement support ---- */
 /* Per-stage device time (HIP events on the launch stream), accumulated while profiling is on. */

@@ -11,9 +11,10 @@
  *     exactly as the reference compresses a fresh raw stream of that chunk, separated by full-flush markers.
  *     It is a valid RFC 1950 stream that any inflate() reads; it is not byte-identical to the reference's
  *     unchunked output, whose matches cross 64 KiB boundaries.
- *   - Served parameters: method Z_DEFLATED, windowBits 15 (zlib wrapper) or -15 (raw), memLevel 8,
- *     Z_DEFAULT_STRATEGY, levels 0..9 and Z_DEFAULT_COMPRESSION.  Anything else returns Z_STREAM_ERROR
- *     (gzip wrapper, preset dictionaries, deflateParams/Tune/Prime/Copy are "next" rows of SURVEY.md 8f).
+ *   - Served parameters: method Z_DEFLATED, windowBits 15 (zlib wrapper), -15 (raw) or 31 (gzip wrapper with the
+ *     default header; inflate also 47 = zlib or gzip, detected), memLevel 8, Z_DEFAULT_STRATEGY, levels 0..9 and
+ *     Z_DEFAULT_COMPRESSION.  Anything else returns Z_STREAM_ERROR (preset dictionaries, deflateSetHeader /
+ *     inflateGetHeader, deflateParams/Tune/Prime/Copy are "next" rows of SURVEY.md 8f).
  *   - There is no CPU codec behind this API: without a usable GPU, the Init functions return Z_MEM_ERROR with
  *     strm->msg explaining why.
  */
@@ -120,6 +121,8 @@ int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLe
 
 uLong adler32(uLong adler, const Bytef *buf, uInt len);
 uLong adler32_combine(uLong adler1, uLong adler2, z_off_t len2);
+uLong crc32(uLong crc, const Bytef *buf, uInt len);
+uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2);
 
 #define deflateInit(strm, level) deflateInit_((strm), (level), ZLIB_VERSION, (int)sizeof(z_stream))
 #define inflateInit(strm) inflateInit_((strm), ZLIB_VERSION, (int)sizeof(z_stream))

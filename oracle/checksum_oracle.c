@@ -43,3 +43,36 @@ uint32_t ora_crc32(uint32_t crc, const uint8_t *buf, size_t len)
     }
     return c ^ 0xffffffffu;
 }
+
+/* crc32_combine, crc32.c:343-423: the CRC register after len2 further zero bytes is a linear map of the register, applied
+ * as a 32x32 bit matrix over GF(2) that is squared once per bit of len2 (operator for 1 zero bit -> 2 -> 4 -> 8 = one byte
+ * -> 2 bytes ...), then crc2 is added. */
+static uint32_t ora_gf2_apply(const uint32_t *mat, uint32_t vec)
+{
+    uint32_t sum = 0;
+    for (int i = 0; vec; vec >>= 1, i++) if (vec & 1) sum ^= mat[i];
+    return sum;
+}
+static void ora_gf2_square(uint32_t *dst, const uint32_t *mat)
+{
+    for (int n = 0; n < 32; n++) dst[n] = ora_gf2_apply(mat, mat[n]);
+}
+uint32_t ora_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    uint32_t even[32], odd[32];
+    if (len2 == 0) return crc1;
+    odd[0] = 0xedb88320u; /* one zero bit: shift right, feed the polynomial back */
+    for (int n = 1; n < 32; n++) odd[n] = 1u << (n - 1);
+    ora_gf2_square(even, odd); /* two zero bits */
+    ora_gf2_square(odd, even); /* four */
+    do {
+        ora_gf2_square(even, odd); /* first pass: eight zero bits = one byte */
+        if (len2 & 1) crc1 = ora_gf2_apply(even, crc1);
+        len2 >>= 1;
+        if (len2 == 0) break;
+        ora_gf2_square(odd, even);
+        if (len2 & 1) crc1 = ora_gf2_apply(odd, crc1);
+        len2 >>= 1;
+    } while (len2 != 0);
+    return crc1 ^ crc2;
+}

@@ -66,6 +66,7 @@ uint32_t ora_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
 
 /* crc32.c:219-251 (bitwise restatement) and :370-423 */
 uint32_t ora_crc32(uint32_t crc, const uint8_t *buf, size_t len);
+uint32_t ora_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 
 /* Raw inflate of a complete deflate stream (inflate.c:554-1153 with wrap==0, inffast.c, inftrees.c).
  * Decodes until the final block ends.  *used / *produced report progress.  Returns ORA_STREAM_END on

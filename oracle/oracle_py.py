@@ -41,6 +41,8 @@ def lib():
         L.ora_adler32_combine.restype = C.c_uint32
         L.ora_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
         L.ora_crc32.restype = C.c_uint32
+        L.ora_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.ora_crc32_combine.restype = C.c_uint32
         for f in (L.ora_inflate_raw, L.ora_inflate_zlib):
             f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                           C.POINTER(C.c_size_t), C.POINTER(C.c_char_p)]
@@ -90,6 +92,22 @@ def adler32_combine(a1, a2, len2):
 
 def crc32(data: bytes, start: int = 0) -> int:
     return lib().ora_crc32(start, data, len(data))
+
+
+def crc32_combine(c1, c2, len2):
+    return lib().ora_crc32_combine(c1, c2, len2)
+
+
+def gzip_header(level: int) -> bytes:
+    """The 10 bytes deflate() writes for windowBits 31 when no gz_header was set (reference deflate.c:578-596); OS_CODE 3."""
+    return bytes([31, 139, 8, 0, 0, 0, 0, 0, 2 if level == 9 else 4 if level < 2 else 0, 3])
+
+
+def deflate_stream_gzip(data, level: int, chunk: int = 65536) -> bytes:
+    """Mode B body in a gzip member: header, the raw chunk streams of deflate_stream, CRC-32 and length (deflate.c:833-843)."""
+    z = deflate_stream(data, level, chunk)  # zlib-wrapped: 2-byte header, body, 4-byte Adler
+    raw = bytes(data) if isinstance(data, (bytes, bytearray)) else data.tobytes()
+    return gzip_header(level) + z[2:-4] + crc32(raw).to_bytes(4, "little") + (len(raw) & 0xFFFFFFFF).to_bytes(4, "little")
 
 
 def _inflate(fn, data: bytes, outcap: int):

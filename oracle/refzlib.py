@@ -97,6 +97,54 @@ def adler32(data: bytes, start: int = 1) -> int:
     return a
 
 
+def crc32(data: bytes, start: int = 0) -> int:
+    L = lib()
+    L.crc32.argtypes = [C.c_ulong, C.c_char_p, C.c_uint]
+    L.crc32.restype = C.c_ulong
+    return L.crc32(start, data, len(data)) & 0xFFFFFFFF
+
+
+def crc32_combine(c1: int, c2: int, len2: int) -> int:
+    L = lib()
+    L.crc32_combine.argtypes = [C.c_ulong, C.c_ulong, C.c_long]
+    L.crc32_combine.restype = C.c_ulong
+    return L.crc32_combine(c1, c2, len2) & 0xFFFFFFFF
+
+
+def deflate_wbits(data: bytes, level: int, wbits: int) -> bytes:
+    """One-shot deflate with the reference at the given windowBits (31: gzip wrapper)."""
+    L = lib()
+    s = ZStream()
+    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, wbits, 8, 0, b"1.2.3", C.sizeof(ZStream))
+    assert rc == Z_OK, rc
+    cap = len(data) + (len(data) >> 8) + 1024
+    out = C.create_string_buffer(cap)
+    inb = C.create_string_buffer(data, max(len(data), 1))
+    s.next_in = C.addressof(inb); s.avail_in = len(data)
+    s.next_out = C.addressof(out); s.avail_out = cap
+    rc = L.deflate(C.byref(s), Z_FINISH)
+    assert rc == Z_STREAM_END, rc
+    n = s.total_out
+    L.deflateEnd(C.byref(s))
+    return out.raw[:n]
+
+
+def inflate_wbits(data: bytes, wbits: int, outcap: int):
+    """One-shot inflate with the reference at the given windowBits; returns (rc, bytes, consumed, msg, strm.adler)."""
+    L = lib()
+    s = ZStream()
+    rc = L.inflateInit2_(C.byref(s), wbits, b"1.2.3", C.sizeof(ZStream))
+    assert rc == Z_OK, rc
+    out = C.create_string_buffer(max(outcap, 1))
+    inb = C.create_string_buffer(data, max(len(data), 1))
+    s.next_in = C.addressof(inb); s.avail_in = len(data)
+    s.next_out = C.addressof(out); s.avail_out = outcap
+    rc = L.inflate(C.byref(s), Z_FINISH)
+    res = (rc, out.raw[:s.total_out], s.total_in, s.msg.decode() if s.msg else None, s.adler & 0xFFFFFFFF)
+    L.inflateEnd(C.byref(s))
+    return res
+
+
 def deflate_chunk_raw(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False) -> bytes:
     """The per-chunk function F(bytes, level, pos0_matchable, is_last) of SURVEY.md section 8c, computed
     by the real reference: a fresh raw stream (windowBits=-15, memLevel=8, default strategy) fed the

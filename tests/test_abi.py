@@ -50,7 +50,7 @@ def test_host_library_exports_and_fails_loudly_without_gpu():
     import zhost as Z
     text = open(os.path.join(ROOT, "include", "zamd_zlib.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = sorted(set(re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_]*)\s*\(z_streamp|\b(compress2?|uncompress|compressBound|adler32(?:_combine)?|zlibVersion|zError|zlibCompileFlags)\s*\(", text)))
+    names = sorted(set(re.findall(r"\b([a-zA-Z_][a-zA-Z0-9_]*)\s*\(z_streamp|\b(compress2?|uncompress|compressBound|adler32(?:_combine)?|crc32(?:_combine)?|zlibVersion|zError|zlibCompileFlags)\s*\(", text)))
     flat = sorted({n for pair in names for n in pair if n})
     L = Z.lib()
     assert len(flat) >= 20

@@ -38,7 +38,7 @@ struct ChunkMeta {
     uint32_t data_type;   // Z_BINARY 0 / Z_TEXT 1 / Z_UNKNOWN 2 from the first non-empty block
     uint32_t adler_a, adler_b; // Adler-32 halves of the chunk bytes, as if started from 1
     uint32_t in_bytes;
-    uint32_t pad;
+    uint32_t crc;         // CRC-32 of the chunk bytes (crc_kernel; gzip wrapper only)
 };
 
 // Where the chunks of one launch live.  Either uniform (chunk k = bytes [k*chunk_size, ...)) or an explicit

@@ -9,12 +9,13 @@
 
 namespace zgpu {
 
-struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow; };
+struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 // kernels (other translation units)
 void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
+void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
                    uint64_t out_cap, uint32_t slot_stride, hipStream_t st);
@@ -165,7 +166,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
     const uint32_t chunk_size = p->chunk_size ? p->chunk_size : kChunkMax;
     if (chunk_size > kChunkMax) return fail(e, ZGPU_STREAM_ERROR, "chunk_size must be 1..65536");
-    if ((p->flags & ZGPU_F_ZLIB_WRAP) && !(p->flags & ZGPU_F_FINAL)) return fail(e, ZGPU_STREAM_ERROR, "ZLIB_WRAP needs FINAL");
+    if ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) && !(p->flags & ZGPU_F_FINAL)) return fail(e, ZGPU_STREAM_ERROR, "a wrapper needs FINAL");
+    if ((p->flags & ZGPU_F_ZLIB_WRAP) && (p->flags & ZGPU_F_GZIP_WRAP)) return fail(e, ZGPU_STREAM_ERROR, "one wrapper at a time");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
     const LevelCfg cfg = level_cfg(p->level);
     int impl = p->lz_impl;
@@ -174,7 +176,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     const bool serial = impl == ZGPU_LZ_SERIAL;
-    if (d_seg && ((p->flags & ZGPU_F_ZLIB_WRAP) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
+    if (d_seg && ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
     // One batch = one launch of every stage.  The lane-per-chunk stages (serial LZ77, parse) need tens of thousands of
     // chunks in flight to fill 256 CUs, so batches are as large as device memory allows (~1 MiB of workspace per chunk).
@@ -192,20 +194,25 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
     int rc = ensure_deflate_ws(e, batch, serial, nchunks);
     if (rc) return rc;
-    const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP;
+    const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP, gz = p->flags & ZGPU_F_GZIP_WRAP;
+    const uint32_t head_bytes = wrap ? 2 : gz ? 10 : 0, tail_bytes = wrap ? 4 : gz ? 8 : 0;
     ChunkGeom g{};
     g.in = d_in; g.in_bytes = in_bytes; g.seg_off = d_seg; g.chunk_size = chunk_size;
     g.final_chunk = (!d_seg && (p->flags & ZGPU_F_FINAL)) ? nchunks - 1 : ~0ull;
     g.all_final = (d_seg && (p->flags & ZGPU_F_FINAL)) ? 1u : 0u;
     g.pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
-    const uint64_t body_cap = wrap ? (out_cap >= 6 ? out_cap - 4 : 0) : out_cap;
+    const uint64_t body_cap = tail_bytes ? (out_cap >= head_bytes + tail_bytes ? out_cap - tail_bytes : 0) : out_cap;
 
-    RunStateHost rs{}; rs.out_total = wrap ? 2 : 0; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
+    RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
     const bool check_sort = impl == ZGPU_LZ_SORTED && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
+    if (gz && out_cap >= 10) { // the header deflate() writes when no gz_header was set (qcsrc/deflate.c:578-596); OS_CODE 3 as the reference builds here
+        const uint8_t hdr[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(p->level == 9 ? 2 : p->level < 2 ? 4 : 0), 3};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 10, hipMemcpyHostToDevice, st));
+    }
 
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
@@ -226,6 +233,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         {
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
             launch_adler(g, e->meta, st);
+            if (gz || (p->flags & ZGPU_F_CRC32)) launch_crc(g, e->meta, st);
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st);
             launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);
         }
@@ -239,7 +247,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         e->exact_sort = 1;
         return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st);
     }
-    if (rs.overflow || (wrap && out_cap < rs.out_total + 4)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    if (rs.overflow || (tail_bytes && out_cap < rs.out_total + tail_bytes)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
     if (wrap) {
         uint8_t tr[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
@@ -247,11 +255,20 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         ZGPU_HIP_CHECK(hipStreamSynchronize(st));
         rs.out_total += 4;
     }
+    if (gz) { // CRC-32 and the input length mod 2^32, both little-endian (qcsrc/deflate.c:833-843)
+        const uint32_t isz = (uint32_t)in_bytes;
+        uint8_t tr[8] = {(uint8_t)rs.crc, (uint8_t)(rs.crc >> 8), (uint8_t)(rs.crc >> 16), (uint8_t)(rs.crc >> 24),
+                         (uint8_t)isz, (uint8_t)(isz >> 8), (uint8_t)(isz >> 16), (uint8_t)(isz >> 24)};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_out + rs.out_total, tr, 8, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        rs.out_total += 8;
+    }
     if (d_chunk_offsets) {
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_chunk_offsets, e->offsets, (nchunks + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     }
     res->out_bytes = rs.out_total; res->nchunks = nchunks; res->adler32 = adler; res->data_type = rs.data_type; res->ntokens = rs.ntokens;
+    res->crc32 = (gz || (p->flags & ZGPU_F_CRC32)) ? rs.crc : 0;
     return ZGPU_OK;
 }
 
@@ -441,6 +458,35 @@ int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uin
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     hipFree(meta); hipFree(offs);
     *adler_out = rs.adler_a | (rs.adler_b << 16);
+    return ZGPU_OK;
+}
+
+int zgpu_crc32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *crc_out, void *hip_stream)
+{
+    if (!e || !crc_out || (!d_in && in_bytes)) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    const uint64_t nchunks = in_bytes ? (in_bytes + kChunkMax - 1) / kChunkMax : 1;
+    const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
+    int rc = ensure_deflate_ws(e, 1, false, 1);
+    if (rc) return rc;
+    ChunkMeta *meta = nullptr;
+    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&meta), (size_t)batch * sizeof(ChunkMeta)));
+    uint64_t *offs = nullptr;
+    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&offs), (nchunks + 1) * sizeof(uint64_t)));
+    RunStateHost rs{}; rs.adler_a = 1;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
+        ChunkGeom g{}; g.in = static_cast<const uint8_t *>(d_in); g.in_bytes = in_bytes; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
+        launch_crc(g, meta, st);
+        launch_scan(meta, nb, c0, offs, e->run, ~0ull, st);
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    hipFree(meta); hipFree(offs);
+    *crc_out = rs.crc;
     return ZGPU_OK;
 }
 

@@ -25,6 +25,7 @@ int fail_hip(zgpu_engine *e, hipError_t err, const char *what, const char *file,
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
+void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
                    uint64_t out_cap, uint32_t slot_stride, hipStream_t st);
@@ -471,7 +472,7 @@ uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
 int engine_device(zgpu_engine *e);
 void engine_collect(zgpu_engine *e);
 int engine_fail(zgpu_engine *e, int code, const char *msg);
-struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow; };
+struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
@@ -488,7 +489,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     if (!meta) return engine_fail(e, ZGPU_MEM_ERROR, "inflate meta");
     uint8_t *slots = nullptr;
     if (compact) { slots = static_cast<uint8_t *>(engine_scratch2(e, (size_t)batch * kChunkMax + 256)); if (!slots) return engine_fail(e, ZGPU_MEM_ERROR, "inflate slots"); }
-    res->adler32 = 1; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0; res->out_bytes = 0;
+    res->adler32 = 1; res->crc32 = 0; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0; res->out_bytes = 0;
     ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(uint64_t), st));
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
@@ -525,12 +526,14 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
         ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
         launch_adler(g, meta, st);
+        launch_crc(g, meta, st);
         launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st);
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, engine_run_state(e), sizeof rs, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     engine_collect(e);
     res->adler32 = rs.adler_a | (rs.adler_b << 16);
+    res->crc32 = rs.crc;
     return ZGPU_OK;
 }
 } // namespace zgpu

@@ -18,6 +18,7 @@ struct RunState {
     uint32_t adler_a, adler_b; // Adler-32 halves of all input so far (a starts at 1, b at 0)
     uint32_t data_type;
     uint32_t overflow;         // set when the output capacity was exceeded
+    uint32_t crc, pad;         // CRC-32 of all input so far (meaningful when the chunks' crc fields were filled)
 };
 
 // ---- Adler-32 of each chunk: A = 1 + sum b_i, B = n + sum (n - i) b_i (mod 65521) ----
@@ -58,6 +59,75 @@ __global__ void __launch_bounds__(256) adler_kernel(ChunkGeom g, ChunkMeta *meta
     }
 }
 
+
+// ---- CRC-32 (the reference's crc32.c:219-335 and crc32_combine :370-423, as polynomial arithmetic) ----
+// Reflected CRC-32 polynomial; a 32-bit word holds a polynomial over GF(2) with x^0 in bit 31.
+constexpr uint32_t kCrcPoly = 0xedb88320u;
+__host__ __device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) // a(x) * b(x) mod P(x)
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t crc_xpow8n(uint64_t n) // x^(8n) mod P: the operator "append n zero bytes"
+{
+    uint32_t r = 0x80000000u, sq = 0x00800000u; // x^0, x^8
+    while (n) {
+        if (n & 1) r = crc_mulmod(sq, r);
+        sq = crc_mulmod(sq, sq);
+        n >>= 1;
+    }
+    return r;
+}
+// CRC of X||Y from the finished CRCs of X and Y and |Y| (what crc32_combine computes with its 32x32 bit matrices)
+__host__ __device__ inline uint32_t crc_join(uint32_t cx, uint32_t cy, uint32_t op_leny) { return crc_mulmod(op_leny, cx) ^ cy; }
+
+// One 256-lane workgroup per chunk.  Lane t takes a slice of L = ceil(n/256) bytes, slices aligned to the END of the chunk
+// (so every right-hand operand of the tree below has a full power-of-two number of slices and one operator per level
+// serves all lanes; the short or empty slices are on the left, where length does not matter), table-driven bytewise
+// (crc32.c:242-266 without the 4-byte variant: the table lives in LDS), then an 8-level tree of joins.
+__global__ void __launch_bounds__(256) crc_kernel(ChunkGeom g, ChunkMeta *meta)
+{
+    __shared__ uint32_t table[256];
+    __shared__ uint32_t part[256];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    if (c >= g.nchunks) return;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    {
+        uint32_t r = tid;
+#pragma unroll
+        for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ kCrcPoly : r >> 1;
+        table[tid] = r;
+    }
+    __syncthreads();
+    const uint32_t L = (n + 255) / 256;
+    const int64_t hi = (int64_t)n - (int64_t)(255 - tid) * L, lo_b = hi - L; // [lo_b, hi) clipped to [0, n)
+    uint32_t crc = 0;
+    if (hi > 0) {
+        crc = 0xffffffffu;
+        for (int64_t i = lo_b > 0 ? lo_b : 0; i < hi; i++) crc = table[(crc ^ src[i]) & 255u] ^ (crc >> 8);
+        crc ^= 0xffffffffu;
+    }
+    part[tid] = crc;
+    uint32_t op = crc_xpow8n(L); // append L bytes
+    __syncthreads();
+    for (uint32_t s = 1; s < 256; s <<= 1) {
+        uint32_t v = 0;
+        const bool mine = (tid & (2 * s - 1)) == 0;
+        if (mine) v = crc_join(part[tid], part[tid + s], op); // the right operand covers exactly s slices: s*L bytes
+        __syncthreads();
+        if (mine) part[tid] = v;
+        op = crc_mulmod(op, op);
+        __syncthreads();
+    }
+    if (tid == 0) { meta[c].crc = part[0]; meta[c].in_bytes = n; }
+}
+
 // Adler of X||Y from Adler(X) = (ax, bx), Adler(Y) = (ay, by), |Y| = ny:  a = ax + ay - 1,  b = bx + by + ny (ax - 1)
 __device__ inline void adler_join(uint32_t &ax, uint32_t &bx, uint32_t ay, uint32_t by, uint64_t ny)
 {
@@ -74,22 +144,29 @@ __global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict_
     __shared__ uint64_t part[1024];
     __shared__ uint32_t pa[1024], pb[1024];
     __shared__ uint64_t plen[1024], ptok[1024];
+    __shared__ uint32_t pcrc[1024];
     const uint32_t tid = threadIdx.x, per = (nchunks + 1023) / 1024;
     const uint32_t a = tid * per < nchunks ? tid * per : nchunks, z = (tid + 1) * per < nchunks ? (tid + 1) * per : nchunks;
-    uint64_t sum = 0, len = 0, ntok = 0; uint32_t xa = 1, xb = 0;
+    uint64_t sum = 0, len = 0, ntok = 0; uint32_t xa = 1, xb = 0, xc = 0;
+    uint32_t op_len = ~0u, op = 0; // the append operator of the last chunk length seen (chunks are the same size but for the last)
     for (uint32_t i = a; i < z; i++) {
         sum += meta[i].out_bytes; ntok += meta[i].ntok;
         adler_join(xa, xb, meta[i].adler_a, meta[i].adler_b, meta[i].in_bytes); len += meta[i].in_bytes;
+        if (meta[i].in_bytes != op_len) { op_len = meta[i].in_bytes; op = crc_xpow8n(op_len); }
+        xc = crc_join(xc, meta[i].crc, op);
     }
-    part[tid] = sum; pa[tid] = xa; pb[tid] = xb; plen[tid] = len; ptok[tid] = ntok;
+    part[tid] = sum; pa[tid] = xa; pb[tid] = xb; plen[tid] = len; ptok[tid] = ntok; pcrc[tid] = xc;
     __syncthreads();
     if (tid == 0) {
-        uint64_t acc = run->out_total, tl = 0, tt = 0; uint32_t ra = run->adler_a, rb = run->adler_b;
+        uint64_t acc = run->out_total, tl = 0, tt = 0; uint32_t ra = run->adler_a, rb = run->adler_b, rc = run->crc;
+        uint64_t opl = ~0ull; uint32_t opv = 0;
         for (uint32_t t = 0; t < 1024; t++) {
             uint64_t s = part[t]; part[t] = acc; acc += s;
             adler_join(ra, rb, pa[t], pb[t], plen[t]); tl += plen[t]; tt += ptok[t];
+            if (plen[t] != opl) { opl = plen[t]; opv = crc_xpow8n(opl); }
+            rc = crc_join(rc, pcrc[t], opv);
         }
-        run->out_total = acc; run->adler_a = ra; run->adler_b = rb; run->in_total += tl; run->ntokens += tt;
+        run->out_total = acc; run->adler_a = ra; run->adler_b = rb; run->crc = rc; run->in_total += tl; run->ntokens += tt;
         if (chunk0 == 0 && nchunks > 0) run->data_type = meta[0].data_type;
         if (acc > out_cap) run->overflow = 1;
         offsets[chunk0 + nchunks] = acc;
@@ -130,6 +207,11 @@ __global__ void __launch_bounds__(64) corpus_kernel(uint32_t kind, uint64_t seed
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nchunks) zc_fill_chunk(kind, seed, first_chunk + i, out + i * ZC_CHUNK);
+}
+
+void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)
+{
+    hipLaunchKernelGGL(crc_kernel, dim3(g.nchunks), dim3(256), 0, st, g, meta);
 }
 
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)

@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL = 1, 2, 4, 8
+F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL, F_GZIP_WRAP, F_CRC32 = 1, 2, 4, 8, 16, 32
 LZ_AUTO, LZ_SERIAL, LZ_PARALLEL, LZ_SORTED = 0, 1, 2, 3
 STAGES = ["chain", "match", "parse", "lz_serial", "huffman", "stitch", "inflate"]
 CHUNK = 65536
@@ -23,12 +23,12 @@ class _Params(C.Structure):
 
 class DeflateResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("nchunks", C.c_uint64), ("adler32", C.c_uint32), ("data_type", C.c_uint32),
-                ("ntokens", C.c_uint64)]
+                ("ntokens", C.c_uint64), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class InflateResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("adler32", C.c_uint32), ("first_bad_chunk", C.c_int32),
-                ("error_code", C.c_int32), ("error_msg", C.c_uint32)]
+                ("error_code", C.c_int32), ("error_msg", C.c_uint32), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def library_path():
@@ -72,6 +72,7 @@ def load_library():
     L.zgpu_inflate_message.argtypes = [u32]
     L.zgpu_inflate_message.restype = C.c_char_p
     L.zgpu_adler32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
+    L.zgpu_crc32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
     L.zgpu_profile_enable.argtypes = [vp, C.c_int]
     L.zgpu_profile_enable.restype = None
     L.zgpu_profile_reset.argtypes = [vp]
@@ -194,6 +195,11 @@ class Engine:
     def adler32_device(self, d_in, n, stream=None):
         a = C.c_uint32(0)
         self._check(self.L.zgpu_adler32_device(self.h, d_in, n, C.byref(a), stream))
+        return a.value
+
+    def crc32_device(self, d_in, n, stream=None):
+        a = C.c_uint32(0)
+        self._check(self.L.zgpu_crc32_device(self.h, d_in, n, C.byref(a), stream))
         return a.value
 
     def corpus_fill_device(self, kind, seed, first_chunk, nchunks, d_out, stream=None):

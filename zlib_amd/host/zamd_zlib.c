@@ -109,6 +109,39 @@ static uint32_t adler_join(uint32_t x, uint32_t y, uint64_t leny)
     return (uint32_t)(a | (b << 16));
 }
 
+/* ---- CRC-32 (crc32.c:219-266 bytewise with one table; crc32_combine :370-423 as polynomial arithmetic mod P) ---- */
+static uint32_t g_crc_table[256];
+static pthread_once_t g_crc_once = PTHREAD_ONCE_INIT;
+static void crc_table_init(void)
+{
+    for (uint32_t i = 0; i < 256; i++) { uint32_t r = i; for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ 0xedb88320u : r >> 1; g_crc_table[i] = r; }
+}
+EXPORT uLong crc32(uLong crc, const Bytef *buf, uInt len)
+{
+    if (buf == Z_NULL) return 0;
+    pthread_once(&g_crc_once, crc_table_init);
+    uint32_t c = (uint32_t)crc ^ 0xffffffffu;
+    while (len--) c = g_crc_table[(c ^ *buf++) & 255u] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+static uint32_t crc_mulmod(uint32_t a, uint32_t b) /* a(x) b(x) mod P(x), x^0 in bit 31 */
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) { if (a & m) p ^= b; b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1; }
+    return p;
+}
+static uint32_t crc_join(uint32_t cx, uint32_t cy, uint64_t leny) /* CRC of X||Y */
+{
+    uint32_t r = 0x80000000u, sq = 0x00800000u; /* x^0, x^8 */
+    for (uint64_t n = leny; n; n >>= 1) { if (n & 1) r = crc_mulmod(sq, r); sq = crc_mulmod(sq, sq); }
+    return crc_mulmod(r, cx) ^ cy;
+}
+EXPORT uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2)
+{
+    if (len2 == 0) return crc1; /* crc32.c:383-384 */
+    return crc_join((uint32_t)crc1, (uint32_t)crc2, (uint64_t)len2);
+}
+
 /* ---- stream state ---- */
 enum { KIND_DEFLATE = 0x5a44, KIND_INFLATE = 0x5a49 };
 enum { ST_INIT = 1, ST_BUSY = 2, ST_FINISH = 3, ST_DONE = 4, ST_BAD = 5 };
@@ -121,6 +154,7 @@ struct internal_state {
     int trailer_done; /* deflate: Adler trailer already appended */
     int any_block;    /* deflate: at least one chunk has been emitted */
     uint32_t adler;   /* Adler-32 of the uncompressed data that went through the GPU (deflate) / was produced (inflate) */
+    uint32_t crc;     /* the same for CRC-32 (gzip wrapper, wrap == 2) */
     int decoded;      /* inflate: the body has been decoded */
     size_t next_try;  /* inflate: do not re-try a decode before this many bytes have been collected */
 };
@@ -133,7 +167,11 @@ static uLong bound_for(uLong n)
     return ref > ours ? ref : ours;
 }
 EXPORT uLong compressBound(uLong sourceLen) { return bound_for(sourceLen); }
-EXPORT uLong deflateBound(z_streamp strm, uLong sourceLen) { (void)strm; return bound_for(sourceLen); }
+EXPORT uLong deflateBound(z_streamp strm, uLong sourceLen)
+{
+    const int gz = strm != Z_NULL && strm->state != Z_NULL && strm->state->kind == KIND_DEFLATE && strm->state->wrap == 2;
+    return bound_for(sourceLen) + (gz ? 12 : 0); /* 18 bytes of gzip framing instead of the 6 of zlib (deflate.c:520-534) */
+}
 
 static struct internal_state *state_new(z_streamp strm, int kind)
 {
@@ -174,6 +212,7 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     if (level == Z_DEFAULT_COMPRESSION) level = 6;
     int wrap = 1;
     if (windowBits < 0) { wrap = 0; windowBits = -windowBits; }
+    else if (windowBits > 15) { wrap = 2; windowBits -= 16; } /* gzip wrapper, deflate.c:251-254 */
     /* served subset: see include/zamd_zlib.h */
     if (method != Z_DEFLATED || windowBits != 15 || memLevel != 8 || strategy != Z_DEFAULT_STRATEGY || level < 0 || level > 9) return Z_STREAM_ERROR;
     if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
@@ -194,7 +233,7 @@ EXPORT int deflateReset(z_streamp strm)
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->data_type = Z_UNKNOWN;
     s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0;
     s->status = s->wrap ? ST_INIT : ST_BUSY; s->last_flush = Z_NO_FLUSH;
-    s->adler = 1; strm->adler = 1;
+    s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
     return Z_OK;
 }
 EXPORT int deflateEnd(z_streamp strm)
@@ -234,14 +273,17 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     struct internal_state *s = strm->state;
     if (s->level == 0) {
         if (!stored_chunks(&s->out, src, n, final)) return Z_MEM_ERROR;
-        for (size_t o = 0; o < n; o += 0x40000000u) { size_t m = n - o < 0x40000000u ? n - o : 0x40000000u; s->adler = (uint32_t)adler32(s->adler, src + o, (uInt)m); }
+        for (size_t o = 0; o < n; o += 0x40000000u) {
+            size_t m = n - o < 0x40000000u ? n - o : 0x40000000u;
+            if (s->wrap == 2) s->crc = (uint32_t)crc32(s->crc, src + o, (uInt)m); else s->adler = (uint32_t)adler32(s->adler, src + o, (uInt)m);
+        }
         s->any_block = 1; return Z_OK;
     }
     zgpu_engine *e = engine_get();
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     uint64_t cap = zgpu_deflate_bound(n, CHUNK);
     if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
-    zgpu_deflate_params p = {s->level, CHUNK, final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO};
+    zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO};
     zgpu_deflate_result r;
     pthread_mutex_lock(&g_lock);
     int rc = zgpu_deflate_host(e, src, n, &p, s->out.p + s->out.len, cap, NULL, &r);
@@ -249,6 +291,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
     s->out.len += r.out_bytes;
     s->adler = adler_join(s->adler, r.adler32, n); /* computed on the GPU with the chunks (deflate.c:968-970) */
+    if (s->wrap == 2) s->crc = crc_join(s->crc, r.crc32, n);
     if (!s->any_block && n > 0) strm->data_type = (int)r.data_type; /* the first block decides (trees.c:934-935) */
     s->any_block = 1;
     return Z_OK;
@@ -265,6 +308,11 @@ EXPORT int deflate(z_streamp strm, int flush)
     int old_flush = s->last_flush;
     s->last_flush = flush;
 
+    if (s->status == ST_INIT && s->wrap == 2) { /* gzip header without a gz_header, deflate.c:578-596; OS_CODE 3 as the reference builds on this host */
+        const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : s->level < 2 ? 4 : 0), 3};
+        if (!buf_put(&s->out, h, 10)) return Z_MEM_ERROR;
+        s->status = ST_BUSY;
+    }
     if (s->status == ST_INIT) { /* zlib header, deflate.c:625-649 */
         unsigned hdr = (Z_DEFLATED + (7u << 4)) << 8, lf = s->level < 2 ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
         hdr |= lf << 6; hdr += 31 - hdr % 31;
@@ -303,13 +351,22 @@ EXPORT int deflate(z_streamp strm, int flush)
         }
         if (rc != Z_OK) return rc;
         /* strm->adler covers every byte read so far: what the GPU has checksummed plus the (< 64 KiB) buffered tail */
-        if (s->wrap) strm->adler = s->in.len ? adler_join(s->adler, (uint32_t)adler32(1, s->in.p, (uInt)s->in.len), s->in.len) : s->adler;
+        if (s->wrap == 2) strm->adler = s->in.len ? crc_join(s->crc, (uint32_t)crc32(0, s->in.p, (uInt)s->in.len), s->in.len) : s->crc;
+        else if (s->wrap) strm->adler = s->in.len ? adler_join(s->adler, (uint32_t)adler32(1, s->in.p, (uInt)s->in.len), s->in.len) : s->adler;
         deliver(strm);
         if (strm->avail_out == 0 && (s->out.len - s->out_pos != 0 || flush != Z_FINISH)) { s->last_flush = -1; return Z_OK; }
     }
     if (flush != Z_FINISH) return Z_OK;
     if (s->out.len - s->out_pos != 0) { s->last_flush = -1; return Z_OK; }
     if (!s->wrap || s->trailer_done) return Z_STREAM_END;
+    if (s->wrap == 2) { /* trailer, deflate.c:833-843: CRC-32 and total_in, least significant byte first */
+        const uint32_t c = s->crc, l = (uint32_t)strm->total_in;
+        uint8_t t8[8] = {(uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24), (uint8_t)l, (uint8_t)(l >> 8), (uint8_t)(l >> 16), (uint8_t)(l >> 24)};
+        if (!buf_put(&s->out, t8, 8)) return Z_MEM_ERROR;
+        s->trailer_done = 1;
+        deliver(strm);
+        return s->out.len - s->out_pos != 0 ? Z_OK : Z_STREAM_END;
+    }
     /* trailer, deflate.c:847-855 */
     uint8_t t[4] = {(uint8_t)(s->adler >> 24), (uint8_t)(s->adler >> 16), (uint8_t)(s->adler >> 8), (uint8_t)s->adler};
     if (!buf_put(&s->out, t, 4)) return Z_MEM_ERROR;
@@ -326,7 +383,8 @@ EXPORT int inflateInit2_(z_streamp strm, int windowBits, const char *version, in
     strm->msg = Z_NULL;
     int wrap = 1;
     if (windowBits < 0) { wrap = 0; windowBits = -windowBits; }
-    if (windowBits < 8 || windowBits > 15) return Z_STREAM_ERROR;
+    else if (windowBits > 15) { wrap = (windowBits >> 4) + 1; windowBits &= 15; } /* inflate.c:158-164: 2 gzip only, 3 zlib or gzip */
+    if (windowBits < 8 || windowBits > 15 || wrap > 3) return Z_STREAM_ERROR;
     if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     struct internal_state *s = state_new(strm, KIND_INFLATE);
     if (!s) return Z_MEM_ERROR;
@@ -340,7 +398,7 @@ EXPORT int inflateReset(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->adler = 1;
-    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->decoded = 0; s->status = ST_BUSY; s->adler = 1; s->next_try = 0;
+    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->decoded = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0;
     return Z_OK;
 }
 EXPORT int inflateEnd(z_streamp strm)
@@ -357,16 +415,35 @@ static int decode_all(z_streamp strm, size_t out_hint)
 {
     struct internal_state *s = strm->state;
     const uint8_t *p = s->in.p; size_t n = s->in.len, skip = 0;
-    if (s->wrap) { /* inflate.c:589-632 */
+    int gz = 0;
+    if ((s->wrap & 2) && n >= 2 && p[0] == 31 && p[1] == 139) { /* gzip header, inflate.c:596-602, 634-759 */
+        gz = 1;
+        if (n < 10) return Z_BUF_ERROR;
+        if (p[2] != Z_DEFLATED) { strm->msg = (char *)"unknown compression method"; return Z_DATA_ERROR; }
+        if (p[3] & 0xe0) { strm->msg = (char *)"unknown header flags set"; return Z_DATA_ERROR; }
+        const unsigned flg = p[3];
+        skip = 10;
+        if (flg & 4) { if (n < skip + 2) return Z_BUF_ERROR; skip += 2 + ((size_t)p[skip] | ((size_t)p[skip + 1] << 8)); if (n < skip) return Z_BUF_ERROR; }
+        if (flg & 8) { while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
+        if (flg & 16) { while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
+        if (flg & 2) {
+            if (n < skip + 2) return Z_BUF_ERROR;
+            const uint32_t hc = (uint32_t)crc32(0, p, (uInt)skip) & 0xffffu;
+            if (hc != ((uint32_t)p[skip] | ((uint32_t)p[skip + 1] << 8))) { strm->msg = (char *)"header crc mismatch"; return Z_DATA_ERROR; }
+            skip += 2;
+        }
+        if (n < skip + 8 + 2) return Z_BUF_ERROR;
+    } else if (s->wrap) { /* inflate.c:589-632 */
         if (n < 2) return Z_BUF_ERROR;
-        if ((((unsigned)p[0] << 8) + p[1]) % 31) { strm->msg = (char *)"incorrect header check"; return Z_DATA_ERROR; }
+        if (!(s->wrap & 1) || (((unsigned)p[0] << 8) + p[1]) % 31) { strm->msg = (char *)"incorrect header check"; return Z_DATA_ERROR; }
         if ((p[0] & 15) != Z_DEFLATED) { strm->msg = (char *)"unknown compression method"; return Z_DATA_ERROR; }
         if ((unsigned)(p[0] >> 4) + 8 > (unsigned)s->level) { strm->msg = (char *)"invalid window size"; return Z_DATA_ERROR; }
         if (p[1] & 0x20) return Z_NEED_DICT;
         skip = 2;
         if (n < skip + 4 + 2) return Z_BUF_ERROR;
     }
-    size_t body = n - skip - (s->wrap ? 4 : 0);
+    const size_t tail = gz ? 8 : s->wrap ? 4 : 0;
+    size_t body = n - skip - tail;
     if (body == 0) return Z_BUF_ERROR;
     zgpu_engine *e = engine_get();
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
@@ -387,10 +464,16 @@ static int decode_all(z_streamp strm, size_t out_hint)
             strm->msg = (char *)m; return Z_DATA_ERROR;
         }
         if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
-        s->out.len = r.out_bytes; s->adler = r.adler32;
+        s->out.len = r.out_bytes; s->adler = gz ? r.crc32 : r.adler32; /* strm->adler is the CRC for a gzip stream (inflate.c:602) */
         break;
     }
-    if (s->wrap) { /* inflate.c:1077-1098 */
+    if (gz) { /* inflate.c:1083-1112: CRC-32, then the length mod 2^32, both least significant byte first */
+        const uint8_t *t = p + n - 8;
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t wlen = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (want != s->adler) { strm->msg = (char *)"incorrect data check"; s->out.len = 0; return Z_DATA_ERROR; }
+        if (wlen != (uint32_t)s->out.len) { strm->msg = (char *)"incorrect length check"; s->out.len = 0; return Z_DATA_ERROR; }
+    } else if (s->wrap) { /* inflate.c:1077-1098 */
         const uint8_t *t = p + n - 4;
         uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
         if (want != s->adler) { strm->msg = (char *)"incorrect data check"; s->out.len = 0; return Z_DATA_ERROR; }
