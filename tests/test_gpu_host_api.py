@@ -33,7 +33,10 @@ def test_version_and_errors():
     assert L.deflateInit_(C.byref(s), 6, b"2.0", C.sizeof(Z.ZStream)) == Z.Z_VERSION_ERROR      # deflate.c:236-239
     assert L.deflateInit_(C.byref(s), 6, b"1.2.3", 100) == Z.Z_VERSION_ERROR
     assert L.deflateInit_(C.byref(s), 10, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR
-    assert L.deflateInit2_(C.byref(s), 6, 8, 31, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # gzip wrapper: not served
+    assert L.deflateInit2_(C.byref(s), 6, 8, 14, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # window sizes other than 32 KiB: not served
+    assert L.deflateInit2_(C.byref(s), 6, 8, 15, 9, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # memLevel 9 changes the block cut: not served
+    assert L.deflateInit2_(C.byref(s), 6, 8, 31, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK            # gzip wrapper (tests/test_gpu_gzip.py)
+    assert L.deflateEnd(C.byref(s)) == Z.Z_OK
     assert L.deflateInit_(C.byref(s), 6, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
     out = C.create_string_buffer(16)
     s.next_out = C.addressof(out); s.avail_out = 0
