@@ -414,6 +414,23 @@ __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32
     }
 }
 
+// Lane masks straight from a vector compare (SGPR pair).  `__ballot(a && b)` of two conditions goes through
+// v_cndmask + v_cmp_ne to rebuild a mask the compares had already produced; the walk step below keeps the set of lanes
+// still walking as such a mask and combines compare results with scalar ANDs.
+__device__ inline unsigned long long mask_eq_u32(uint32_t a, uint32_t b) { unsigned long long m; asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ inline unsigned long long mask_le_i32(int a, int b) { unsigned long long m; asm volatile("v_cmp_le_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ inline unsigned long long mask_gt_u32(uint32_t a, uint32_t b) { unsigned long long m; asm volatile("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ inline unsigned long long mask_lt_i32(int a, int b) { unsigned long long m; asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+// the lanes of m append `entry` to the wave's stack at LDS byte offset rt, in lane order (exec is narrowed inside the block only)
+__device__ inline void stack_push(unsigned long long m, uint32_t rt, uint32_t entry)
+{
+    unsigned long long sv; uint32_t t;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\t"
+                 "v_mbcnt_lo_u32_b32 %1, %3, 0\n\tv_mbcnt_hi_u32_b32 %1, %4, %1\n\tv_lshl_add_u32 %1, %1, 2, %5\n\t"
+                 "ds_write_b32 %1, %6\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv), "=&v"(t) : "s"(m), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(rt), "v"(entry) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------- K2''
 // Lockstep form of the same search.  A wave takes 64 CONSECUTIVE entries of S (one work item = one block of 64 S
 // indices); lane L searches position S[wi], wi = 64*blk + L, and all lanes examine their k-th candidate S[wi-1-k] in the
@@ -500,7 +517,8 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         uint32_t best = kMinMatch - 1, key_seen = 0, snapkey = 0;
         uint32_t scan2 = (uint32_t)d8[p + 1] | ((uint32_t)d8[p + 2] << 8);
         uint32_t boff = dbase + best - 1;
-        bool active = avail != 0, snap_taken = false;
+        unsigned long long amask = mask_gt_u32(avail, 0u); // lanes still walking (wave-uniform)
+        bool snap_taken = false;
         const uint16_t *sp = S + wi; // candidate k is sp[-1-k]
         lds_st32(slot + lane * 4, 0);
         lds_st16(pw + lane * 2, p);
@@ -535,42 +553,45 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
             const uint32_t key = lds_ld32(slot + lane * 4);
             if (key != key_seen) {
                 key_seen = key;
-                if (key >> 31) { best = key & 0x1ffu; active = false; }
-                else best = key >> 16;
+                best = (key >> 31) ? key & 0x1ffu : key >> 16;
                 boff = dbase + best - 1;
                 scan2 = (uint32_t)d8[p + best - 1] | ((uint32_t)d8[p + best] << 8);
             }
+            amask &= ~mask_lt_i32((int)key, 0); // a nice_match key: the walk of that lane is over (deflate.c:1224)
         };
 
-        uint64_t cq = 0; // four candidates, the nearest in the top 16 bits
-        if (active) cq = reinterpret_cast<const U64u *>(sp - 4)->v;
+        // four candidates per load, the nearest in the top 16 bits; the index is clamped so that lanes whose walk is over load
+        // something harmless instead of being masked off
+        auto group = [&](uint32_t k0) -> uint64_t {
+            int gi = (int)wi - 4 - (int)k0;
+            gi = gi < -(int)kSPad ? -(int)kSPad : gi;
+            return reinterpret_cast<const U64u *>(S + gi)->v;
+        };
+        uint64_t cq = group(0);
         uint32_t k = 0;
         for (;; k += 4) {
-            if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+            if (amask == 0) break;
             if (k == chainQ) {
                 while (tail) fold(k);
                 snapkey = key_seen; snap_taken = true;
             } else if ((k & (ZGPU_M3_PERIOD - 1)) == 0) { while (tail) fold(k); }
-            uint64_t cqn = 0;
-            if (active && k + 4 < avail) cqn = reinterpret_cast<const U64u *>(sp - 8 - k)->v;
+            const uint64_t cqn = group(k + 4);
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                // no divergent control flow in the step: idle lanes read a harmless in-range address and are masked out of the ballot
+                // no divergent control flow in the step: every lane reads (idle ones a harmless in-range address), masks decide
                 const uint32_t q = (uint32_t)(cq >> (48 - 16 * j)) & 0xffffu;
                 uint32_t b0, b1;
                 lds_ld2bytes(boff + q, b0, b1);
-                active = active && (int)q >= thr; // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
+                amask &= mask_le_i32(thr, (int)q); // beyond MAX_DIST (or the NIL position): the chain ends here (deflate.c:1163)
                 if (k == 0 && j == 0) thr = thr_next;
-                const bool pass = active && (b0 | (b1 << 8)) == scan2;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                M3_STAT(0, 1); M3_STAT(1, __popcll(__builtin_amdgcn_ballot_w64(active))); M3_STAT(2, __popcll(m));
+                const unsigned long long m = amask & mask_eq_u32(b0 | (b1 << 8), scan2);
+                M3_STAT(0, 1); M3_STAT(1, __popcll(amask)); M3_STAT(2, __popcll(m));
                 if (m) {
-                    const uint32_t rt = (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2));
-                    if (pass) lds_st32(rt + (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << 2), q | lanebits | ((k + j) << 22));
+                    stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), q | lanebits | ((k + j) << 22));
                     tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
                     if (tail >= 64) fold(k + j);
                 }
-                active = active && k + j + 1 < avail;
+                amask &= mask_gt_u32(avail, k + j + 1);
             }
             cq = cqn;
         }
