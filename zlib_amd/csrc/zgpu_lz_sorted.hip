@@ -421,14 +421,14 @@ __device__ inline unsigned long long mask_eq_u32(uint32_t a, uint32_t b) { unsig
 __device__ inline unsigned long long mask_le_i32(int a, int b) { unsigned long long m; asm volatile("v_cmp_le_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ inline unsigned long long mask_gt_u32(uint32_t a, uint32_t b) { unsigned long long m; asm volatile("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
 __device__ inline unsigned long long mask_lt_i32(int a, int b) { unsigned long long m; asm volatile("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-// the lanes of m append `entry` to the wave's stack at LDS byte offset rt, in lane order (exec is narrowed inside the block only)
-__device__ inline void stack_push(unsigned long long m, uint32_t rt, uint32_t entry)
+// the lanes of m append `entry` to the wave's stack at LDS byte offset rt, in lane order; the other lanes store to a dummy
+// word instead (narrowing exec for the store costs more than the select: writes to exec stall the vector pipe)
+__device__ inline void stack_push(unsigned long long m, uint32_t rt, uint32_t dummy, uint32_t entry)
 {
-    unsigned long long sv; uint32_t t;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\t"
-                 "v_mbcnt_lo_u32_b32 %1, %3, 0\n\tv_mbcnt_hi_u32_b32 %1, %4, %1\n\tv_lshl_add_u32 %1, %1, 2, %5\n\t"
-                 "ds_write_b32 %1, %6\n\ts_mov_b64 exec, %0"
-                 : "=&s"(sv), "=&v"(t) : "s"(m), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(rt), "v"(entry) : "memory");
+    uint32_t t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, %2, 0\n\tv_mbcnt_hi_u32_b32 %0, %3, %0\n\tv_lshl_add_u32 %0, %0, 2, %4\n\t"
+                 "v_cndmask_b32_e64 %0, %5, %0, %1\n\tds_write_b32 %0, %6"
+                 : "=&v"(t) : "s"(m), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(rt), "v"(dummy), "v"(entry) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------- K2''
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         lds_st32(slot + lane * 4, 0);
         lds_st16(pw + lane * 2, p);
         uint32_t tail = 0; // entries on the ring (wave-uniform)
-        const uint32_t lanebits = lane << 16;
+        const uint32_t lanebits = lane << 16, dummy = ring + (kRing - 1) * 4; // (the stack never holds more than 127 entries: its last word is free)
         M3_STAT(5, __popcll(__builtin_amdgcn_ballot_w64(valid)));
 
         // fold up to 64 ring entries into their owners' slots, then let every owner pick up its new best length
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
                 const unsigned long long m = amask & mask_eq_u32(b0 | (b1 << 8), scan2);
                 M3_STAT(0, 1); M3_STAT(1, __popcll(amask)); M3_STAT(2, __popcll(m));
                 if (m) {
-                    stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), q | lanebits | ((k + j) << 22));
+                    stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, q | lanebits | ((k + j) << 22));
                     tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
                     if (tail >= 64) fold(k + j);
                 }
