@@ -16,7 +16,7 @@ void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
-void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st);
+void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st, bool with_crc = false);
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
                    uint64_t out_cap, uint32_t slot_stride, hipStream_t st);
 void launch_corpus(uint32_t kind, uint64_t seed, uint64_t first_chunk, uint64_t nchunks, uint8_t *out, hipStream_t st);
@@ -234,7 +234,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
             launch_adler(g, e->meta, st);
             if (gz || (p->flags & ZGPU_F_CRC32)) launch_crc(g, e->meta, st);
-            launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st);
+            launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st, gz || (p->flags & ZGPU_F_CRC32));
             launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);
         }
         ZGPU_HIP_CHECK(hipGetLastError());
@@ -481,7 +481,7 @@ int zgpu_crc32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint3
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
         ChunkGeom g{}; g.in = static_cast<const uint8_t *>(d_in); g.in_bytes = in_bytes; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
         launch_crc(g, meta, st);
-        launch_scan(meta, nb, c0, offs, e->run, ~0ull, st);
+        launch_scan(meta, nb, c0, offs, e->run, ~0ull, st, true);
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));

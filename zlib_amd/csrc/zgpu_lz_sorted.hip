@@ -12,11 +12,12 @@
 // link ring in LDS (the match kernel needs only the 64 KiB chunk there, so two 1024-lane workgroups fit a CU instead
 // of one), no tiles and no per-tile barriers (any position can be searched at any time).
 //
-//   K1' sort_kernel    one wave per chunk: rank(p) by a sequential pass over count[h] in LDS (64 positions per step,
-//                      duplicates inside a step resolved with ballots), exclusive scan of the counts, scatter to S.
-//   K2' match2_kernel  one 1024-lane workgroup per chunk, lanes = positions, the state machine of zgpu_lz_parallel.hip
-//                      with rounds of four candidates.
-//   K3                 parse_kernel of zgpu_lz_parallel.hip, unchanged (same record format).
+//   K1'' sort3_kernel   the sort: ranks by ordered LDS atomics under a wave token, scatter staged through LDS, self-check;
+//                       output S (u16 positions), one bit per S index marking bucket heads, heads_below per 64 indices
+//   K1'  sort_kernel    the same result with ballots only (6x slower): fallback when sort3's self-check fails, ZGPU_SORT=1
+//   K2'' match3_kernel  one 1024-lane workgroup per chunk, a wave per 64 consecutive S entries, all lanes on their k-th
+//                       candidate in the same step, full compares deferred to a per-wave stack and folded with atomic max
+//   K3                  parse2_kernel (zgpu_lz_parse.hip), or parse_kernel of zgpu_lz_parallel.hip with ZGPU_PARSE=1
 #include "zgpu_common.h"
 #include <cstdlib>
 #include "../../include/zamd_gpu.h"

@@ -139,7 +139,7 @@ __device__ inline void adler_join(uint32_t &ax, uint32_t &bx, uint32_t ay, uint3
 
 // One workgroup: exclusive scan of out_bytes over the batch (continuing RunState), ordered Adler combination.
 __global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict__ meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets,
-                                                    RunState *run, uint64_t out_cap)
+                                                    RunState *run, uint64_t out_cap, uint32_t with_crc)
 {
     __shared__ uint64_t part[1024];
     __shared__ uint32_t pa[1024], pb[1024];
@@ -152,8 +152,10 @@ __global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict_
     for (uint32_t i = a; i < z; i++) {
         sum += meta[i].out_bytes; ntok += meta[i].ntok;
         adler_join(xa, xb, meta[i].adler_a, meta[i].adler_b, meta[i].in_bytes); len += meta[i].in_bytes;
-        if (meta[i].in_bytes != op_len) { op_len = meta[i].in_bytes; op = crc_xpow8n(op_len); }
-        xc = crc_join(xc, meta[i].crc, op);
+        if (with_crc) {
+            if (meta[i].in_bytes != op_len) { op_len = meta[i].in_bytes; op = crc_xpow8n(op_len); }
+            xc = crc_join(xc, meta[i].crc, op);
+        }
     }
     part[tid] = sum; pa[tid] = xa; pb[tid] = xb; plen[tid] = len; ptok[tid] = ntok; pcrc[tid] = xc;
     __syncthreads();
@@ -163,8 +165,10 @@ __global__ void __launch_bounds__(1024) scan_kernel(const ChunkMeta *__restrict_
         for (uint32_t t = 0; t < 1024; t++) {
             uint64_t s = part[t]; part[t] = acc; acc += s;
             adler_join(ra, rb, pa[t], pb[t], plen[t]); tl += plen[t]; tt += ptok[t];
-            if (plen[t] != opl) { opl = plen[t]; opv = crc_xpow8n(opl); }
-            rc = crc_join(rc, pcrc[t], opv);
+            if (with_crc) {
+                if (plen[t] != opl) { opl = plen[t]; opv = crc_xpow8n(opl); }
+                rc = crc_join(rc, pcrc[t], opv);
+            }
         }
         run->out_total = acc; run->adler_a = ra; run->adler_b = rb; run->crc = rc; run->in_total += tl; run->ntokens += tt;
         if (chunk0 == 0 && nchunks > 0) run->data_type = meta[0].data_type;
@@ -218,9 +222,9 @@ void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)
 {
     hipLaunchKernelGGL(adler_kernel, dim3(g.nchunks), dim3(256), 0, st, g, meta);
 }
-void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st)
+void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st, bool with_crc)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, meta, nchunks, chunk0, offsets, static_cast<RunState *>(run), out_cap);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, meta, nchunks, chunk0, offsets, static_cast<RunState *>(run), out_cap, with_crc ? 1u : 0u);
 }
 void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *offsets, uint64_t chunk0, uint32_t nchunks, uint8_t *out,
                    uint64_t out_cap, uint32_t slot_stride, hipStream_t st)
