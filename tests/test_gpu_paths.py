@@ -41,7 +41,7 @@ print("DIGESTS " + json.dumps(out, sort_keys=True))
 
 def run_variant(env_extra):
     env = dict(os.environ)
-    for k in ("ZGPU_SORT", "ZGPU_SORT_FAULT_TEST", "ZGPU_PARSE"):
+    for k in ("ZGPU_SORT", "ZGPU_SORT_FAULT_TEST", "ZGPU_PARSE", "ZGPU_BATCH_CHUNKS"):
         env.pop(k, None)
     env.update(env_extra)
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900)
@@ -57,6 +57,7 @@ def test_alternative_paths_agree():
     data = CP.chunks(0, 0, 24).tobytes()
     assert base["corpus0/6"] == hashlib.sha256(O.deflate_stream(data, 6, 65536)).hexdigest()
     assert base["zeros/9"] == hashlib.sha256(O.deflate_stream(bytes(3 * 65536 + 5), 9, 65536)).hexdigest()
-    for env in ({"ZGPU_SORT": "1"}, {"ZGPU_SORT_FAULT_TEST": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}):
+    # ... and a batch size of 7 chunks: every multi-chunk input above then takes several launches of every stage
+    for env in ({"ZGPU_SORT": "1"}, {"ZGPU_SORT_FAULT_TEST": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}, {"ZGPU_BATCH_CHUNKS": "7"}):
         got = run_variant(env)
         assert got == base, "variant %r differs: %s" % (env, [k for k in base if got.get(k) != base[k]])

@@ -180,15 +180,17 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
     // One batch = one launch of every stage.  The lane-per-chunk stages (serial LZ77, parse) need tens of thousands of
     // chunks in flight to fill 256 CUs, so batches are as large as device memory allows (~1 MiB of workspace per chunk).
-    uint32_t batch_max = env_u32("ZGPU_BATCH_CHUNKS", 65536);
+    uint32_t batch_max = env_u32("ZGPU_BATCH_CHUNKS", 65536); // (small values are for tests: several launches per call)
+    if (batch_max == 0) batch_max = 1;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
-            if (budget / per_chunk < batch_max) batch_max = (uint32_t)(budget / per_chunk);
-            if (batch_max < 256) batch_max = 256;
+            size_t fit = budget / per_chunk; // chunks that fit; never below 256, whatever the device reports
+            if (fit < 256) fit = 256;
+            if (fit < batch_max) batch_max = (uint32_t)fit;
         }
     }
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);

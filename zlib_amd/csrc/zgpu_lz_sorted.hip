@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
     uint32_t *hd = heads_all + (size_t)c * kHeadStride;
+    if (tid < kSPad) S[-(int)kSPad + (int)tid] = 0;
     for (uint32_t i = tid; i < kChunkMax / 32; i += kSortThreads) hd[i] = 0; // (pass C sets bits; the barriers of pass A lie in between)
     for (uint32_t i = tid; i < kHashSize / 2; i += kSortThreads) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
@@ -240,6 +241,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
     uint32_t *hd = heads_all + (size_t)c * kHeadStride;
+    if (threadIdx.x < kSPad) S[-(int)kSPad + (int)threadIdx.x] = 0; // the pad reads as "position 0" (match3's finished lanes)
     uint32_t last_of_half0 = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
     const uint32_t cnt_a = lds_off(cnt), tok_a = lds_off(&token);
@@ -563,10 +565,13 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 
         // four candidates per load, the nearest in the top 16 bits; the index is clamped so that lanes whose walk is over load
         // something harmless instead of being masked off
+        // ... and lanes whose walk is over read the zeroed pad in front of S: candidate "position 0" for all of them, so their
+        // (unused) quick-check reads fall on a handful of LDS words instead of 64 random ones (the LDS pipe is 80 % busy)
         auto group = [&](uint32_t k0) -> uint64_t {
-            int gi = (int)wi - 4 - (int)k0;
+            int gi = (int)wi - 4 - (int)k0, gsel;
             gi = gi < -(int)kSPad ? -(int)kSPad : gi;
-            return reinterpret_cast<const U64u *>(S + gi)->v;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(gsel) : "v"(-(int)kSPad), "v"(gi), "s"(amask));
+            return reinterpret_cast<const U64u *>(S + gsel)->v;
         };
         uint64_t cq = group(0);
         uint32_t k = 0;
