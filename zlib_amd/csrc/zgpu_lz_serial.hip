@@ -13,6 +13,7 @@
 // position-0-matchable chunk, off = 32768 once the slide has happened.  An entry is the
 // reference's NIL exactly when its derived index is <= 0.
 #include "zgpu_common.h"
+#include <cstdlib>
 
 namespace zgpu {
 
@@ -122,9 +123,12 @@ __device__ void lz_serial_chunk(SerialLz &s)
 }
 
 // grid: one lane per chunk of the batch.  tables: per chunk 2 x 32768 u16 (head zeroed by the host side).
-__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta)
+__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes)
 {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    // `lanes` chunks per wave: a wave's step takes as long as its slowest lane's memory access, and fewer lanes per wave
+    // means more waves to overlap those waits (the vector work per step is next to nothing)
+    if (threadIdx.x >= lanes) return;
+    uint32_t c = blockIdx.x * lanes + threadIdx.x;
     if (c >= g.nchunks) return;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
@@ -140,7 +144,13 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
 
 void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
 {
-    hipLaunchKernelGGL(lz_serial_kernel, dim3((g.nchunks + 63) / 64), dim3(64), 0, st, g, cfg, tables, tokens, meta);
+    // chunks per wave: measured best (MI355X, level 1) where the launch has about 4096 waves -- 16 per CU; 64 chunks per wave
+    // (1024 waves at 4 GiB) is 30 % slower, 8192 waves again slower.  ZGPU_SERIAL_LANES overrides.
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("ZGPU_SERIAL_LANES"); forced = e ? atoi(e) : 0; if (forced < 0 || forced > 64) forced = 0; }
+    uint32_t lanes = (uint32_t)forced;
+    if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
+    hipLaunchKernelGGL(lz_serial_kernel, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes);
 }
 
 } // namespace zgpu
