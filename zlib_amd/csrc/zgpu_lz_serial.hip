@@ -17,6 +17,9 @@
 
 namespace zgpu {
 
+struct __attribute__((packed, aligned(1))) U32s { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U64s { uint64_t v; };
+
 struct SerialLz {
     const uint8_t *__restrict__ in;
     uint32_t n, base, off;
@@ -31,7 +34,11 @@ struct SerialLz {
 
     __device__ uint32_t insert(uint32_t p)
     {
-        uint32_t h = hash3(in[p], in[p + 1], in[p + 2]);
+        // (every global load of this lane-per-chunk loop is a dependent round trip of several hundred ns even when it hits:
+        // one unaligned dword instead of three byte loads, eight bytes per comparison step instead of one)
+        uint32_t h;
+        if (p + 4 <= n) { const uint32_t v = reinterpret_cast<const U32s *>(in + p)->v; h = hash3(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u); }
+        else h = hash3(in[p], in[p + 1], in[p + 2]);
         uint32_t old = head[h];
         prev[(p + base) & kWMask] = (uint16_t)old;
         head[h] = (uint16_t)(p + 1);
@@ -61,10 +68,17 @@ struct SerialLz {
         do {
             uint32_t q = e - 1;
             const uint8_t *m = in + q;
-            // quick reject on the byte that would extend the best match so far (deflate.c:1121-1124)
-            if (best < cap ? (m[best] == scan[best]) : false) {
+            // quick reject on the byte that would extend the best match so far (deflate.c:1121-1124); with a short best match the
+            // first eight bytes of the comparison cost the same one round trip and say more
+            if (best < cap && (best < 8 || m[best] == scan[best])) {
                 uint32_t l = 0;
+                while (l + 8 <= cap) { // (cap <= look: both reads stay inside the chunk)
+                    const uint64_t x = reinterpret_cast<const U64s *>(m + l)->v ^ reinterpret_cast<const U64s *>(scan + l)->v;
+                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; goto compared; }
+                    l += 8;
+                }
                 while (l < cap && m[l] == scan[l]) l++;
+            compared:
                 if (l > best) { mstart = q; best = l; if (l >= nice) break; }
             }
             e = prev[(q + base) & kWMask];
