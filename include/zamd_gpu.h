@@ -60,6 +60,9 @@ typedef struct {
     uint32_t chunk_size; /* 1..65536; 0 selects 65536 */
     uint32_t flags;      /* ZGPU_F_* */
     int32_t lz_impl;     /* ZGPU_LZ_* */
+    int32_t strategy;    /* 0 Z_DEFAULT_STRATEGY, 1 Z_FILTERED, 2 Z_HUFFMAN_ONLY, 3 Z_RLE, 4 Z_FIXED (qcsrc/deflate.c:1485-1497,
+                            1594-1611; trees.c:986).  Not served by ZGPU_LZ_PARALLEL. */
+    int32_t reserved;
 } zgpu_deflate_params;
 
 typedef struct {

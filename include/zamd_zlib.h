@@ -12,9 +12,9 @@
  *     It is a valid RFC 1950 stream that any inflate() reads; it is not byte-identical to the reference's
  *     unchunked output, whose matches cross 64 KiB boundaries.
  *   - Served parameters: method Z_DEFLATED, windowBits 15 (zlib wrapper), -15 (raw) or 31 (gzip wrapper with the
- *     default header; inflate also 47 = zlib or gzip, detected), memLevel 8, Z_DEFAULT_STRATEGY, levels 0..9 and
- *     Z_DEFAULT_COMPRESSION.  Anything else returns Z_STREAM_ERROR (preset dictionaries, deflateSetHeader /
- *     inflateGetHeader, deflateParams/Tune/Prime/Copy are "next" rows of SURVEY.md 8f).
+ *     default header; inflate also 47 = zlib or gzip, detected), memLevel 8, all five strategies, levels 0..9 and
+ *     Z_DEFAULT_COMPRESSION, deflateParams.  Anything else returns Z_STREAM_ERROR (preset dictionaries,
+ *     deflateSetHeader / inflateGetHeader, deflateTune/Prime/Copy are "next" rows of SURVEY.md 8f).
  *   - There is no CPU codec behind this API: without a usable GPU, the Init functions return Z_MEM_ERROR with
  *     strm->msg explaining why.
  */
@@ -105,7 +105,7 @@ int deflateEnd(z_streamp strm);
 int deflateReset(z_streamp strm);
 uLong deflateBound(z_streamp strm, uLong sourceLen);
 int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength); /* Z_STREAM_ERROR: not served */
-int deflateParams(z_streamp strm, int level, int strategy);                         /* Z_STREAM_ERROR: not served */
+int deflateParams(z_streamp strm, int level, int strategy);
 
 int inflateInit_(z_streamp strm, const char *version, int stream_size);
 int inflateInit2_(z_streamp strm, int windowBits, const char *version, int stream_size);

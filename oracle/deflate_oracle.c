@@ -100,7 +100,7 @@ typedef struct {
 } htree;
 
 typedef struct {
-    const uint8_t *in; uint32_t n, base, off; int level; const level_cfg *cfg;
+    const uint8_t *in; uint32_t n, base, off; int level, strategy; const level_cfg *cfg;
     uint16_t head[HSIZE], prev[WSIZE];
     uint32_t ntok; uint16_t dbuf[LITBUF]; uint8_t lbuf[LITBUF];
     htree lt, dt, bt;
@@ -277,7 +277,7 @@ static void close_block(enc *e, uint32_t p_end, int eof)
     } else opt_lenb = static_lenb = (uint64_t)stored_len + 5;
 
     if ((uint64_t)stored_len + 4 <= opt_lenb && bs_w >= 0) { stored_block(e, e->in + e->block_start, stored_len, eof); btype = 0; }
-    else if (static_lenb == opt_lenb) {
+    else if (e->strategy == ORA_FIXED || static_lenb == opt_lenb) { /* trees.c:986 */
         put_bits(&e->bs, (1u << 1) + (unsigned)eof, 3);
         emit_tokens(e, T_slcode, NULL, T_sllen, T_sdcode, NULL, 5); btype = 1;
     } else {
@@ -343,6 +343,18 @@ static uint32_t best_match(enc *e, uint32_t p, uint32_t cur, uint32_t prev_lengt
     return best <= look ? best : look;
 }
 
+/* longest_match_fast deflate.c:1173-1228 (only reached with strategy Z_RLE in this build: FASTEST is not defined).  No chain,
+ * no seed: the common prefix with the one candidate, MIN_MATCH-1 when shorter than MIN_MATCH, clipped to the lookahead. */
+static uint32_t fast_match(enc *e, uint32_t p, uint32_t cur, uint32_t *match_start)
+{
+    uint32_t q = cur - e->base + e->off, look = e->n - p, cap = look < MAXM ? look : MAXM, l = 0;
+    if (cap < 2 || e->in[q] != e->in[p] || e->in[q + 1] != e->in[p + 1]) return MINM - 1; /* (look >= MIN_MATCH here) */
+    while (l < cap && e->in[q + l] == e->in[p + l]) l++;
+    if (l < MINM) return MINM - 1;
+    *match_start = q;
+    return l;
+}
+
 /* how many bytes the very first fill_window can take: window_size - strstart (deflate.c:1275,1342) */
 static uint32_t first_fill(const enc *e) { uint32_t room = 2 * WSIZE - e->base; return e->n < room ? e->n : room; }
 
@@ -356,8 +368,9 @@ static void run_slow(enc *e, int eof) /* deflate_slow deflate.c:1554-1674 */
         if (look >= MINM) hash_head = insert_at(e, p);
         prev_len = match_len; prev_match = match_start; match_len = MINM - 1;
         if (hash_head != 0 && prev_len < e->cfg->lazy && widx(e, p) - hash_head <= (uint32_t)MAXDIST) {
-            match_len = best_match(e, p, hash_head, prev_len, &match_start);
-            if (match_len <= 5 && match_len == MINM && p - match_start > FAR_LIMIT) match_len = MINM - 1;
+            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) match_len = best_match(e, p, hash_head, prev_len, &match_start);
+            else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) match_len = fast_match(e, p, hash_head, &match_start);
+            if (match_len <= 5 && (e->strategy == ORA_FILTERED || (match_len == MINM && p - match_start > FAR_LIMIT))) match_len = MINM - 1; /* deflate.c:1601-1611 */
         }
         if (prev_len >= MINM && match_len <= prev_len) {
             uint32_t max_insert = p + look - MINM, k = prev_len - 2;
@@ -383,8 +396,10 @@ static void run_fast(enc *e, int eof) /* deflate_fast deflate.c:1448-1546 */
         if (buffered - p < MIN_LOOK) { refill(e, p); buffered = n; if (n - p == 0) break; }
         uint32_t look = n - p;
         if (look >= MINM) hash_head = insert_at(e, p);
-        if (hash_head != 0 && widx(e, p) - hash_head <= (uint32_t)MAXDIST)
-            match_len = best_match(e, p, hash_head, MINM - 1, &match_start);
+        if (hash_head != 0 && widx(e, p) - hash_head <= (uint32_t)MAXDIST) { /* deflate.c:1478-1497 */
+            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) match_len = best_match(e, p, hash_head, MINM - 1, &match_start);
+            else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) match_len = fast_match(e, p, hash_head, &match_start);
+        }
         if (match_len >= MINM) {
             cut = note_match(e, p - match_start, match_len - MINM);
             look -= match_len;
@@ -425,11 +440,17 @@ static void run_stored(enc *e, int eof) /* deflate_stored deflate.c:1390-1439, f
 size_t ora_deflate_chunk(const uint8_t *in, size_t n, int level, int pos0_matchable, int is_last,
                          uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info)
 {
-    if (n > ORA_CHUNK_MAX || level < 0 || level > 9) return 0;
+    return ora_deflate_chunk_s(in, n, level, ORA_DEFAULT_STRATEGY, pos0_matchable, is_last, out, cap, tokens, info);
+}
+
+size_t ora_deflate_chunk_s(const uint8_t *in, size_t n, int level, int strategy, int pos0_matchable, int is_last,
+                           uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info)
+{
+    if (n > ORA_CHUNK_MAX || level < 0 || level > 9 || strategy < 0 || strategy > ORA_FIXED) return 0;
     make_tables();
     enc *e = (enc *)calloc(1, sizeof(enc));
     if (!e) return 0;
-    e->in = in; e->n = (uint32_t)n; e->base = pos0_matchable ? 3u : 0u; e->level = level; e->cfg = &LEVELS[level];
+    e->in = in; e->n = (uint32_t)n; e->base = pos0_matchable ? 3u : 0u; e->level = level; e->strategy = strategy; e->cfg = &LEVELS[level];
     e->bs.out = out; e->bs.cap = cap; e->tok_out = tokens; e->info = info; e->data_type = 2;
     if (info) memset(info, 0, sizeof(*info));
     new_block(e);
@@ -452,15 +473,20 @@ size_t ora_deflate_bound(size_t n, size_t chunk_size)
 
 size_t ora_deflate_stream(const uint8_t *in, size_t n, int level, size_t chunk_size, uint8_t *out, size_t cap)
 {
+    return ora_deflate_stream_s(in, n, level, ORA_DEFAULT_STRATEGY, chunk_size, out, cap);
+}
+
+size_t ora_deflate_stream_s(const uint8_t *in, size_t n, int level, int strategy, size_t chunk_size, uint8_t *out, size_t cap)
+{
     if (chunk_size == 0 || chunk_size > ORA_CHUNK_MAX || cap < 6) return 0;
     /* zlib header, deflate.c:625-641 */
-    unsigned hdr = (8u + (7u << 4)) << 8, lf = level < 2 ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
+    unsigned hdr = (8u + (7u << 4)) << 8, lf = (strategy >= ORA_HUFFMAN_ONLY || level < 2) ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
     hdr |= lf << 6; hdr += 31 - hdr % 31;
     size_t o = 0; out[o++] = (uint8_t)(hdr >> 8); out[o++] = (uint8_t)hdr;
     size_t nchunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     for (size_t k = 0; k < nchunks; k++) {
         size_t lo = k * chunk_size, len = n - lo < chunk_size ? n - lo : chunk_size;
-        size_t got = ora_deflate_chunk(in + lo, len, level, 0, k == nchunks - 1, out + o, cap - o, NULL, NULL);
+        size_t got = ora_deflate_chunk_s(in + lo, len, level, strategy, 0, k == nchunks - 1, out + o, cap - o, NULL, NULL);
         if (got == 0) return 0;
         o += got;
     }

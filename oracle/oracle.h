@@ -49,6 +49,13 @@ typedef struct {
  * (windowBits -15, memLevel 8, Z_DEFAULT_STRATEGY) over in[0..n), n <= 65536, terminated by Z_FINISH
  * (is_last) or Z_FULL_FLUSH (otherwise).  Returns bytes written, or 0 when cap is too small.
  * tokens (optional, capacity >= n) receives the token stream; info is optional. */
+/* strategies, h/zlib.h:176-181 */
+enum { ORA_DEFAULT_STRATEGY = 0, ORA_FILTERED = 1, ORA_HUFFMAN_ONLY = 2, ORA_RLE = 3, ORA_FIXED = 4 };
+
+size_t ora_deflate_chunk_s(const uint8_t *in, size_t n, int level, int strategy, int pos0_matchable, int is_last,
+                           uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info);
+size_t ora_deflate_stream_s(const uint8_t *in, size_t n, int level, int strategy, size_t chunk_size, uint8_t *out, size_t cap);
+
 size_t ora_deflate_chunk(const uint8_t *in, size_t n, int level, int pos0_matchable, int is_last,
                          uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info);
 

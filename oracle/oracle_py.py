@@ -31,6 +31,11 @@ def lib():
         L.ora_deflate_chunk.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p]
         L.ora_deflate_chunk.restype = C.c_size_t
+        L.ora_deflate_chunk_s.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p]
+        L.ora_deflate_chunk_s.restype = C.c_size_t
+        L.ora_deflate_stream_s.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ora_deflate_stream_s.restype = C.c_size_t
         L.ora_deflate_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ora_deflate_stream.restype = C.c_size_t
         L.ora_deflate_bound.argtypes = [C.c_size_t, C.c_size_t]
@@ -51,13 +56,13 @@ def lib():
     return _lib
 
 
-def deflate_chunk(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False, want_tokens=False):
+def deflate_chunk(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False, want_tokens=False, strategy: int = 0):
     L = lib()
     cap = len(chunk) + 512
     out = C.create_string_buffer(cap)
     info = ChunkInfo()
     toks = (Token * max(len(chunk), 1))() if want_tokens else None
-    n = L.ora_deflate_chunk(chunk, len(chunk), level, int(pos0_matchable), int(is_last), out, cap,
+    n = L.ora_deflate_chunk_s(chunk, len(chunk), level, strategy, int(pos0_matchable), int(is_last), out, cap,
                             C.cast(toks, C.c_void_p) if want_tokens else None, C.byref(info))
     if n == 0:
         raise RuntimeError("oracle deflate_chunk failed")
@@ -66,7 +71,7 @@ def deflate_chunk(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool 
     return out.raw[:n]
 
 
-def deflate_stream(data, level: int, chunk: int = 65536) -> bytes:
+def deflate_stream(data, level: int, chunk: int = 65536, strategy: int = 0) -> bytes:
     """data: bytes or a numpy uint8 array (no copy)."""
     L = lib()
     n = len(data)
@@ -76,7 +81,7 @@ def deflate_stream(data, level: int, chunk: int = 65536) -> bytes:
         src = C.cast(C.c_char_p(bytes(data)), C.c_void_p)
     else:
         src = C.c_void_p(data.ctypes.data)
-    got = L.ora_deflate_stream(src, n, level, chunk, out, cap)
+    got = L.ora_deflate_stream_s(src, n, level, strategy, chunk, out, cap)
     if got == 0:
         raise RuntimeError("oracle deflate_stream failed")
     return out.raw[:got]

@@ -111,11 +111,11 @@ def crc32_combine(c1: int, c2: int, len2: int) -> int:
     return L.crc32_combine(c1, c2, len2) & 0xFFFFFFFF
 
 
-def deflate_wbits(data: bytes, level: int, wbits: int) -> bytes:
+def deflate_wbits(data: bytes, level: int, wbits: int, strategy: int = 0) -> bytes:
     """One-shot deflate with the reference at the given windowBits (31: gzip wrapper)."""
     L = lib()
     s = ZStream()
-    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, wbits, 8, 0, b"1.2.3", C.sizeof(ZStream))
+    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, wbits, 8, strategy, b"1.2.3", C.sizeof(ZStream))
     assert rc == Z_OK, rc
     cap = len(data) + (len(data) >> 8) + 1024
     out = C.create_string_buffer(cap)
@@ -145,7 +145,7 @@ def inflate_wbits(data: bytes, wbits: int, outcap: int):
     return res
 
 
-def deflate_chunk_raw(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False) -> bytes:
+def deflate_chunk_raw(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool = False, strategy: int = 0) -> bytes:
     """The per-chunk function F(bytes, level, pos0_matchable, is_last) of SURVEY.md section 8c, computed
     by the real reference: a fresh raw stream (windowBits=-15, memLevel=8, default strategy) fed the
     whole chunk, finished with Z_FINISH (last chunk) or Z_FULL_FLUSH (any other chunk).
@@ -157,7 +157,7 @@ def deflate_chunk_raw(chunk: bytes, level: int, is_last: bool, pos0_matchable: b
     """
     L = lib()
     s = ZStream()
-    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, -15, 8, 0, b"1.2.3", C.sizeof(ZStream))
+    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, -15, 8, strategy, b"1.2.3", C.sizeof(ZStream))
     if rc != Z_OK:
         raise RuntimeError("deflateInit2_ rc=%d" % rc)
     if pos0_matchable:

@@ -71,12 +71,12 @@ def uncompress(z: bytes, cap: int):
     return rc, out.raw[: n.value] if rc == 0 else b""
 
 
-def deflate_stream(data: bytes, level: int, plan, in_step=None, out_step=None, window_bits=15):
+def deflate_stream(data: bytes, level: int, plan, in_step=None, out_step=None, window_bits=15, strategy=0):
     """Drive deflate() like a streaming caller.  plan: list of (nbytes, flush) pieces; in_step/out_step: feed/drain
     granularity inside a piece (None = everything at once).  Returns (bytes, return codes seen, final z_stream)."""
     L = lib()
     s = ZStream()
-    rc = L.deflateInit2_(C.byref(s), level, 8, window_bits, 8, 0, b"1.2.3", C.sizeof(ZStream))
+    rc = L.deflateInit2_(C.byref(s), level, 8, window_bits, 8, strategy, b"1.2.3", C.sizeof(ZStream))
     assert rc == Z_OK, rc
     src = C.create_string_buffer(data, max(len(data), 1))
     cap = L.compressBound(len(data)) + 64 * len(plan) + 1024

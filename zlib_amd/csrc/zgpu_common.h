@@ -21,12 +21,13 @@ constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCode
 constexpr int kEndBlock = 256;
 constexpr uint32_t kSlotStride = 65536 + 256;  // per-chunk output slot (worst case: 5 stored blocks + marker = +30)
 
-struct LevelCfg { uint32_t good, lazy, nice, chain, slow; };
+struct LevelCfg { uint32_t good, lazy, nice, chain, slow, strategy; }; // strategy: Z_DEFAULT_STRATEGY 0 .. Z_FIXED 4 (h/zlib.h:176-181)
+constexpr uint32_t kFiltered = 1, kHuffmanOnly = 2, kRle = 3, kFixed = 4;
 inline LevelCfg level_cfg(int level)
 {
-    static const LevelCfg t[10] = {{0, 0, 0, 0, 0},      {4, 4, 8, 4, 0},      {4, 5, 16, 8, 0},      {4, 6, 32, 32, 0},
-                                   {4, 4, 16, 16, 1},    {8, 16, 32, 32, 1},   {8, 16, 128, 128, 1},  {8, 32, 128, 256, 1},
-                                   {32, 128, 258, 1024, 1}, {32, 258, 258, 4096, 1}};
+    static const LevelCfg t[10] = {{0, 0, 0, 0, 0, 0},      {4, 4, 8, 4, 0, 0},      {4, 5, 16, 8, 0, 0},      {4, 6, 32, 32, 0, 0},
+                                   {4, 4, 16, 16, 1, 0},    {8, 16, 32, 32, 1, 0},   {8, 16, 128, 128, 1, 0},  {8, 32, 128, 256, 1, 0},
+                                   {32, 128, 258, 1024, 1, 0}, {32, 258, 258, 4096, 1, 0}};
     return t[level];
 }
 

@@ -13,7 +13,7 @@ struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, a
 
 // kernels (other translation units)
 void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
-void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st);
+void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st, bool with_crc = false);
@@ -150,9 +150,9 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
     return ZGPU_OK;
 }
 
-static void zlib_header(int level, uint8_t hdr[2]) // qcsrc/deflate.c:625-641
+static void zlib_header(int level, int strategy, uint8_t hdr[2]) // qcsrc/deflate.c:625-641
 {
-    unsigned h = (8u + (7u << 4)) << 8, lf = level < 2 ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
+    unsigned h = (8u + (7u << 4)) << 8, lf = (strategy >= 2 || level < 2) ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
     h |= lf << 6; h += 31 - h % 31;
     hdr[0] = (uint8_t)(h >> 8); hdr[1] = (uint8_t)h;
 }
@@ -169,12 +169,19 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) && !(p->flags & ZGPU_F_FINAL)) return fail(e, ZGPU_STREAM_ERROR, "a wrapper needs FINAL");
     if ((p->flags & ZGPU_F_ZLIB_WRAP) && (p->flags & ZGPU_F_GZIP_WRAP)) return fail(e, ZGPU_STREAM_ERROR, "one wrapper at a time");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
-    const LevelCfg cfg = level_cfg(p->level);
+    if (p->strategy < 0 || p->strategy > (int)kFixed) return fail(e, ZGPU_STREAM_ERROR, "strategy must be 0..4");
+    LevelCfg cfg = level_cfg(p->level);
+    cfg.strategy = (uint32_t)p->strategy;
+    // the chain budget of the all-position search says it all for two strategies (deflate.c:1594-1599): no candidate at all,
+    // or the nearest one only (and then only at distance 1, see match3_kernel)
+    if (cfg.slow && cfg.strategy == kHuffmanOnly) cfg.chain = 0;
+    if (cfg.slow && cfg.strategy == kRle) cfg.chain = 1;
     int impl = p->lz_impl;
     if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_SORTED : ZGPU_LZ_SERIAL;
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
+    if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
     const bool serial = impl == ZGPU_LZ_SERIAL;
     if (d_seg && ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
@@ -210,9 +217,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const bool check_sort = impl == ZGPU_LZ_SORTED && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
-    if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
+    if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, p->strategy, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
     if (gz && out_cap >= 10) { // the header deflate() writes when no gz_header was set (qcsrc/deflate.c:578-596); OS_CODE 3 as the reference builds here
-        const uint8_t hdr[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(p->level == 9 ? 2 : p->level < 2 ? 4 : 0), 3};
+        const uint8_t hdr[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(p->level == 9 ? 2 : (p->strategy >= 2 || p->level < 2) ? 4 : 0), 3};
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 10, hipMemcpyHostToDevice, st));
     }
 
@@ -230,7 +237,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
             ZGPU_HIP_CHECK(hipMemsetAsync(e->slots, 0, (size_t)nb * kSlotStride, st));
-            launch_huffman(g, e->tokens, e->meta, e->slots, st);
+            launch_huffman(g, e->tokens, e->meta, e->slots, st, cfg.strategy == kFixed);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_STITCH);

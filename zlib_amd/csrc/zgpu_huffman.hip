@@ -235,7 +235,7 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     return base + x - v;
 }
 
-__global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots)
+__global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
 {
     __shared__ TreeWork work0;
     __shared__ TreeWorkD work1;
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
             uint32_t btype;
             if (stored_len + 4 <= opt_lenb && !((nostore >> b) & 1)) btype = 0;
-            else if (static_lenb == opt_lenb) btype = 1;
+            else if (fixed_trees || static_lenb == opt_lenb) btype = 1; // Z_FIXED: trees.c:986
             else btype = 2;
             sh_btype = btype;
             // ---- block header ----
@@ -371,9 +371,9 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     }
 }
 
-void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st)
+void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees)
 {
-    hipLaunchKernelGGL(huffman_kernel, dim3(g.nchunks), dim3(kThreads), 0, st, g, tokens, meta, slots);
+    hipLaunchKernelGGL(huffman_kernel, dim3(g.nchunks), dim3(kThreads), 0, st, g, tokens, meta, slots, fixed_trees ? 1u : 0u);
 }
 
 } // namespace zgpu

@@ -407,12 +407,12 @@ __global__ void __launch_bounds__(64) parse_kernel(ChunkGeom g, LevelCfg cfg, co
         const uint2 r = rec[p];
         prev_len = match_len; prev_dist = cur_dist; match_len = kMinMatch - 1;
         if (prev_len < cfg.lazy) {
-            const uint32_t pick = prev_len >= cfg.good ? r.y : r.x;
+            const uint32_t pick = (prev_len >= cfg.good && cfg.strategy != kRle) ? r.y : r.x;
             uint32_t len = pick & 511, dist = (pick >> 9) & 32767;
             if (off != 0 && ((r.y >> 24) & 1)) len = 0; // first candidate became NIL in the slide
             if (len > prev_len) {
                 match_len = len; cur_dist = dist;
-                if (match_len == kMinMatch && cur_dist > kTooFar) match_len = kMinMatch - 1;
+                if (match_len <= 5 && (cfg.strategy == kFiltered || (match_len == kMinMatch && cur_dist > kTooFar))) match_len = kMinMatch - 1;
             }
         }
         bool cut = false;

@@ -34,19 +34,19 @@ constexpr uint32_t kNone = 0xffffffffu;
 
 struct ParseCtx {
     const uint2 *rec;
-    uint32_t n, base, good, lazy;
+    uint32_t n, base, good, lazy, strategy;
     int slide_at; // visited positions >= slide_at see the slid window (off != 0)
     __device__ bool slid(uint32_t p) const { return (int)p >= slide_at; }
     // the match the loop takes at p when the match in hand has length prev_len (deflate.c:1585-1606); 2 = none
     __device__ uint32_t take(uint32_t p, uint32_t prev_len, uint2 r, uint32_t &dist) const
     {
         if (prev_len >= lazy) return kMinMatch - 1;
-        const uint32_t pick = prev_len >= good ? r.y : r.x;
+        const uint32_t pick = (prev_len >= good && strategy != kRle) ? r.y : r.x; // (longest_match_fast has no chain to shorten)
         uint32_t len = pick & 511u;
         const uint32_t d = (pick >> 9) & 32767u;
         if (((r.y >> 24) & 1u) && slid(p)) len = 0; // first candidate became NIL in the slide
         if (len <= prev_len) return kMinMatch - 1;
-        if (len == kMinMatch && d > kTooFar) return kMinMatch - 1;
+        if (len <= 5 && (strategy == kFiltered || (len == kMinMatch && d > kTooFar))) return kMinMatch - 1; // deflate.c:1601-1611
         dist = d;
         return len;
     }
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
     chunk_span(g, c, lo, n);
     ParseCtx cx;
     cx.rec = recs + (size_t)c * kChunkMax;
-    cx.n = n; cx.base = chunk_base(g, c); cx.good = cfg.good; cx.lazy = cfg.lazy;
+    cx.n = n; cx.base = chunk_base(g, c); cx.good = cfg.good; cx.lazy = cfg.lazy; cx.strategy = cfg.strategy;
     {
         // deflate.c:1278-1310 as a function of the position: the first check of "lookahead < MIN_LOOKAHEAD" happens at the first
         // visited p > buffered0 - 262, later ones at p > n - 262; the slide needs p + base >= WSIZE + MAX_DIST on top

@@ -86,6 +86,17 @@ struct SerialLz {
         } while (--chain != 0);
         return best <= look ? best : look;
     }
+    // longest_match_fast (deflate.c:1173-1228; reached with Z_RLE only in this build): the common prefix with the one candidate
+    __device__ uint32_t fast_match(uint32_t p, uint32_t e0, uint32_t &mstart) const
+    {
+        const uint32_t q = e0 - 1, look = n - p, cap = look < kMaxMatch ? look : kMaxMatch;
+        uint32_t l = 0;
+        if (cap < 2 || in[q] != in[p] || in[q + 1] != in[p + 1]) return kMinMatch - 1;
+        while (l < cap && in[q + l] == in[p + l]) l++;
+        if (l < kMinMatch) return kMinMatch - 1;
+        mstart = q;
+        return l;
+    }
 };
 
 template <bool kSlow>
@@ -104,8 +115,9 @@ __device__ void lz_serial_chunk(SerialLz &s)
         if (kSlow) {
             prev_len = match_len; prev_match = mstart; match_len = kMinMatch - 1;
             if (hw > 0 && prev_len < s.cfg.lazy && (uint32_t)(w - hw) <= kMaxDist) {
-                match_len = s.longest(p, hh, prev_len, mstart);
-                if (match_len == kMinMatch && p - mstart > kTooFar) match_len = kMinMatch - 1;
+                if (s.cfg.strategy != kHuffmanOnly && s.cfg.strategy != kRle) match_len = s.longest(p, hh, prev_len, mstart);
+                else if (s.cfg.strategy == kRle && w - hw == 1) match_len = s.fast_match(p, hh, mstart);
+                if (match_len <= 5 && (s.cfg.strategy == kFiltered || (match_len == kMinMatch && p - mstart > kTooFar))) match_len = kMinMatch - 1;
             }
             if (prev_len >= kMinMatch && match_len <= prev_len) {
                 uint32_t max_insert = p + look - kMinMatch, k = prev_len - 2;
@@ -119,7 +131,10 @@ __device__ void lz_serial_chunk(SerialLz &s)
                 p++;
             } else { pending = true; p++; }
         } else {
-            if (hw > 0 && (uint32_t)(w - hw) <= kMaxDist) match_len = s.longest(p, hh, kMinMatch - 1, mstart);
+            if (hw > 0 && (uint32_t)(w - hw) <= kMaxDist) {
+                if (s.cfg.strategy != kHuffmanOnly && s.cfg.strategy != kRle) match_len = s.longest(p, hh, kMinMatch - 1, mstart);
+                else if (s.cfg.strategy == kRle && w - hw == 1) match_len = s.fast_match(p, hh, mstart);
+            }
             if (match_len >= kMinMatch) {
                 cut = s.emit(tok_match(p - mstart, match_len - kMinMatch));
                 look -= match_len;

@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
         const int w = (int)(p + base);
         int thr = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;                 // first candidate: dist <= MAX_DIST, not NIL
         const int thr_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base; // later ones: strictly inside
+        if (cfg.strategy == kRle && thr < (int)p - 1) thr = (int)p - 1; // Z_RLE: the head of the chain counts only at distance 1 (deflate.c:1596)
         uint32_t best = kMinMatch - 1, key_seen = 0, snapkey = 0;
         uint32_t scan2 = (uint32_t)d8[p + 1] | ((uint32_t)d8[p + 2] << 8);
         uint32_t boff = dbase + best - 1;

@@ -147,7 +147,7 @@ enum { KIND_DEFLATE = 0x5a44, KIND_INFLATE = 0x5a49 };
 enum { ST_INIT = 1, ST_BUSY = 2, ST_FINISH = 3, ST_DONE = 4, ST_BAD = 5 };
 
 struct internal_state {
-    int kind, status, wrap, level, last_flush;
+    int kind, status, wrap, level, strategy, last_flush;
     bytebuf in;       /* deflate: input not yet compressed;  inflate: compressed bytes not yet decoded */
     bytebuf out;      /* produced bytes not yet handed to the caller */
     size_t out_pos;   /* first undelivered byte of out */
@@ -214,12 +214,12 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     if (windowBits < 0) { wrap = 0; windowBits = -windowBits; }
     else if (windowBits > 15) { wrap = 2; windowBits -= 16; } /* gzip wrapper, deflate.c:251-254 */
     /* served subset: see include/zamd_zlib.h */
-    if (method != Z_DEFLATED || windowBits != 15 || memLevel != 8 || strategy != Z_DEFAULT_STRATEGY || level < 0 || level > 9) return Z_STREAM_ERROR;
+    if (method != Z_DEFLATED || windowBits != 15 || memLevel != 8 || strategy < 0 || strategy > Z_FIXED || level < 0 || level > 9) return Z_STREAM_ERROR;
     if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     struct internal_state *s = state_new(strm, KIND_DEFLATE);
     if (!s) return Z_MEM_ERROR;
     strm->state = s;
-    s->wrap = wrap; s->level = level;
+    s->wrap = wrap; s->level = level; s->strategy = strategy;
     return deflateReset(strm);
 }
 EXPORT int deflateInit_(z_streamp strm, int level, const char *version, int stream_size)
@@ -244,7 +244,23 @@ EXPORT int deflateEnd(z_streamp strm)
     return busy ? Z_DATA_ERROR : Z_OK; /* deflate.c:886 */
 }
 EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n) { (void)strm; (void)d; (void)n; return Z_STREAM_ERROR; }
-EXPORT int deflateParams(z_streamp strm, int level, int strategy) { (void)strm; (void)level; (void)strategy; return Z_STREAM_ERROR; }
+static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final);
+/* deflate.c:416-451.  What was handed to deflate() so far is compressed with the old parameters (as one more run of chunks,
+ * ending in a flush marker), what follows with the new ones. */
+EXPORT int deflateParams(z_streamp strm, int level, int strategy)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (level == Z_DEFAULT_COMPRESSION) level = 6;
+    if (level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED) return Z_STREAM_ERROR;
+    int rc = Z_OK;
+    if ((level != s->level || strategy != s->strategy) && s->in.len != 0 && s->status != ST_FINISH) {
+        rc = run_chunks(strm, s->in.p, s->in.len, 0);
+        s->in.len = 0;
+    }
+    s->level = level; s->strategy = strategy;
+    return rc;
+}
 
 /* level 0 needs no match finder or entropy coder: stored blocks are framing.  One chunk = the bytes the reference's
  * deflate_stored emits for a fresh stream of that chunk (deflate.c:1390-1439): blocks of at most 65531 bytes, the rest,
@@ -283,7 +299,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     uint64_t cap = zgpu_deflate_bound(n, CHUNK);
     if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
-    zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO};
+    zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
     zgpu_deflate_result r;
     pthread_mutex_lock(&g_lock);
     int rc = zgpu_deflate_host(e, src, n, &p, s->out.p + s->out.len, cap, NULL, &r);
@@ -309,12 +325,12 @@ EXPORT int deflate(z_streamp strm, int flush)
     s->last_flush = flush;
 
     if (s->status == ST_INIT && s->wrap == 2) { /* gzip header without a gz_header, deflate.c:578-596; OS_CODE 3 as the reference builds on this host */
-        const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : s->level < 2 ? 4 : 0), 3};
+        const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 4 : 0), 3};
         if (!buf_put(&s->out, h, 10)) return Z_MEM_ERROR;
         s->status = ST_BUSY;
     }
     if (s->status == ST_INIT) { /* zlib header, deflate.c:625-649 */
-        unsigned hdr = (Z_DEFLATED + (7u << 4)) << 8, lf = s->level < 2 ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
+        unsigned hdr = (Z_DEFLATED + (7u << 4)) << 8, lf = (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
         hdr |= lf << 6; hdr += 31 - hdr % 31;
         uint8_t h[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
         if (!buf_put(&s->out, h, 2)) return Z_MEM_ERROR;
