@@ -42,37 +42,47 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sample, level, threads):
-    """Time the reference (oracle/_ref) -- or the CPU restatement -- per 64 KiB chunk on `threads` host threads."""
+def cpu_baseline(sample, level, threads, op="deflate"):
+    """Time the reference (oracle/_ref) -- or the CPU restatement -- per 64 KiB chunk on `threads` host threads.
+    op "inflate": the chunks are compressed first (untimed) and the timed part is the reference's inflate of those streams."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import refzlib, oracle_py
     use_ref = refzlib.available()
     nchunks = len(sample) // 65536
     if use_ref:
         refzlib.lib()
-
-        def work(r):
-            n = 0
-            for k in r:
-                n += len(refzlib.deflate_chunk_raw(sample[k * 65536:(k + 1) * 65536], level, False))
-            return n
+        enc = lambda b: refzlib.deflate_chunk_raw(b, level, True)
+        dec = lambda z: refzlib.inflate_raw(z, 65536)[1]
     else:
         oracle_py.lib()
+        enc = lambda b: oracle_py.deflate_chunk(b, level, True)
+        dec = lambda z: oracle_py.inflate_raw(z, 65536)[1]
+    parts = [range(t, nchunks, threads) for t in range(threads)]
+    if op == "inflate":
+        with ThreadPoolExecutor(threads) as ex:
+            streams = sum(ex.map(lambda r: [(k, enc(sample[k * 65536:(k + 1) * 65536])) for k in r], parts), [])
+        streams = dict(streams)
 
         def work(r):
             n = 0
             for k in r:
-                n += len(oracle_py.deflate_chunk(sample[k * 65536:(k + 1) * 65536], level, False))
+                n += len(dec(streams[k]))
             return n
-    parts = [range(t, nchunks, threads) for t in range(threads)]
+    else:
+        def work(r):
+            n = 0
+            for k in r:
+                n += len(enc(sample[k * 65536:(k + 1) * 65536]))
+            return n
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         out_bytes = sum(ex.map(work, parts))
     dt = time.perf_counter() - t0
+    what = "inflate of the level-%d streams of the" % level if op == "inflate" else "level %d over the" % level
     return {"value": round(len(sample) / dt / 2**30, 4), "unit": "GiB/s", "cores": threads,
             "kind": "reference" if use_ref else "port",
-            "sample": "first %d MiB of the workload, 64 KiB chunks, level %d, %.1f s wall, ratio %.3f" % (
-                len(sample) >> 20, level, dt, len(sample) / out_bytes)}
+            "sample": "%s first %d MiB of the workload, 64 KiB chunks, %.1f s wall%s" % (
+                what, len(sample) >> 20, dt, "" if op == "inflate" else ", ratio %.3f" % (len(sample) / out_bytes))}
 
 
 def main():
@@ -209,7 +219,7 @@ def main():
             sample_bytes = min(nbytes, a.cpu_sample_mib << 20)
             sample = src[:sample_bytes].cpu().numpy().tobytes()
             threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(sample, a.level, threads)
+            line["cpu_baseline"] = cpu_baseline(sample, a.level, threads, a.op)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
