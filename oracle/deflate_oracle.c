@@ -100,7 +100,7 @@ typedef struct {
 } htree;
 
 typedef struct {
-    const uint8_t *in; uint32_t n, base, off; int level, strategy; const level_cfg *cfg;
+    const uint8_t *in; uint32_t n, base, off, start; int level, strategy; const level_cfg *cfg; /* start: bytes of preset dictionary in front of the data */
     uint16_t head[HSIZE], prev[WSIZE];
     uint32_t ntok; uint16_t dbuf[LITBUF]; uint8_t lbuf[LITBUF];
     htree lt, dt, bt;
@@ -360,7 +360,7 @@ static uint32_t first_fill(const enc *e) { uint32_t room = 2 * WSIZE - e->base; 
 
 static void run_slow(enc *e, int eof) /* deflate_slow deflate.c:1554-1674 */
 {
-    uint32_t p = 0, n = e->n, buffered = first_fill(e), match_len = MINM - 1, prev_len, match_start = 0, prev_match, hash_head = 0;
+    uint32_t p = e->start, n = e->n, buffered = first_fill(e), match_len = MINM - 1, prev_len, match_start = 0, prev_match, hash_head = 0;
     int pending = 0, cut;
     for (;;) {
         if (buffered - p < MIN_LOOK) { refill(e, p); buffered = n; if (n - p == 0) break; }
@@ -390,7 +390,7 @@ static void run_slow(enc *e, int eof) /* deflate_slow deflate.c:1554-1674 */
 
 static void run_fast(enc *e, int eof) /* deflate_fast deflate.c:1448-1546 */
 {
-    uint32_t p = 0, n = e->n, buffered = first_fill(e), match_len = MINM - 1, match_start = 0, hash_head = 0;
+    uint32_t p = e->start, n = e->n, buffered = first_fill(e), match_len = MINM - 1, match_start = 0, hash_head = 0;
     int cut;
     for (;;) {
         if (buffered - p < MIN_LOOK) { refill(e, p); buffered = n; if (n - p == 0) break; }
@@ -417,7 +417,7 @@ static void run_fast(enc *e, int eof) /* deflate_fast deflate.c:1448-1546 */
 static void run_stored(enc *e, int eof) /* deflate_stored deflate.c:1390-1439, fill_window :1266-1358 */
 {
     const uint32_t max_block = 65536 - 5 < 0xffff ? 65536 - 5 : 0xffff; /* pending_buf_size-5, deflate.c:1397-1402 */
-    uint32_t p = 0, look = 0, taken = 0; /* p: strstart (chunk coords); taken: bytes read so far */
+    uint32_t p = e->start, look = 0, taken = e->start; /* p: strstart (chunk coords); taken: bytes read so far (a preset dictionary is already in the window) */
     for (;;) {
         if (look <= 1) {
             do { /* fill_window */
@@ -446,6 +446,16 @@ size_t ora_deflate_chunk(const uint8_t *in, size_t n, int level, int pos0_matcha
 size_t ora_deflate_chunk_s(const uint8_t *in, size_t n, int level, int strategy, int pos0_matchable, int is_last,
                            uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info)
 {
+    return ora_deflate_chunk_d(in, n, 0, level, strategy, pos0_matchable, is_last, out, cap, tokens, info);
+}
+
+/* The same with a preset dictionary (deflateSetDictionary, deflate.c:315-354): `in` holds the dictionary bytes the window
+ * receives (at most MAX_DIST of them, at least MIN_MATCH) followed by the data, n counts both; every dictionary position
+ * but the last two is in the hash chains before the first byte of data is looked at, and strstart = block_start = dict_len. */
+size_t ora_deflate_chunk_d(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, int pos0_matchable, int is_last,
+                           uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info)
+{
+    if (dict_len > n || (dict_len != 0 && (dict_len < MINM || dict_len > MAXDIST || pos0_matchable))) return 0;
     if (n > ORA_CHUNK_MAX || level < 0 || level > 9 || strategy < 0 || strategy > ORA_FIXED) return 0;
     make_tables();
     enc *e = (enc *)calloc(1, sizeof(enc));
@@ -454,6 +464,8 @@ size_t ora_deflate_chunk_s(const uint8_t *in, size_t n, int level, int strategy,
     e->bs.out = out; e->bs.cap = cap; e->tok_out = tokens; e->info = info; e->data_type = 2;
     if (info) memset(info, 0, sizeof(*info));
     new_block(e);
+    e->start = (uint32_t)dict_len; e->block_start = e->start;
+    for (uint32_t q = 0; q + MINM <= e->start; q++) insert_at(e, q); /* deflate.c:345-351 */
     if (e->cfg->mode == 2) run_slow(e, is_last); else if (e->cfg->mode == 1) run_fast(e, is_last); else run_stored(e, is_last);
     if (!is_last) { /* Z_FULL_FLUSH marker: _tr_stored_block(s,0,0,0), deflate.c:811-812 */
         put_bits(&e->bs, 0, 3); byte_align(&e->bs);

@@ -55,6 +55,8 @@ enum { ORA_DEFAULT_STRATEGY = 0, ORA_FILTERED = 1, ORA_HUFFMAN_ONLY = 2, ORA_RLE
 size_t ora_deflate_chunk_s(const uint8_t *in, size_t n, int level, int strategy, int pos0_matchable, int is_last,
                            uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info);
 size_t ora_deflate_stream_s(const uint8_t *in, size_t n, int level, int strategy, size_t chunk_size, uint8_t *out, size_t cap);
+size_t ora_deflate_chunk_d(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, int pos0_matchable, int is_last,
+                           uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info);
 
 size_t ora_deflate_chunk(const uint8_t *in, size_t n, int level, int pos0_matchable, int is_last,
                          uint8_t *out, size_t cap, ora_token *tokens, ora_chunk_info *info);

@@ -34,6 +34,9 @@ def lib():
         L.ora_deflate_chunk_s.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_void_p]
         L.ora_deflate_chunk_s.restype = C.c_size_t
+        L.ora_deflate_chunk_d.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p]
+        L.ora_deflate_chunk_d.restype = C.c_size_t
         L.ora_deflate_stream_s.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ora_deflate_stream_s.restype = C.c_size_t
         L.ora_deflate_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -68,6 +71,21 @@ def deflate_chunk(chunk: bytes, level: int, is_last: bool, pos0_matchable: bool 
         raise RuntimeError("oracle deflate_chunk failed")
     if want_tokens:
         return out.raw[:n], info, [(toks[i].dist, toks[i].lc) for i in range(info.ntokens)]
+    return out.raw[:n]
+
+
+def deflate_chunk_dict(dictionary: bytes, chunk: bytes, level: int, is_last: bool, strategy: int = 0) -> bytes:
+    """The chunk function with a preset dictionary (its last MAX_DIST bytes count, deflate.c:336-339); len(chunk) + the
+    dictionary bytes used must not exceed 65536."""
+    d = dictionary[-32506:]
+    if len(d) < 3:
+        return deflate_chunk(chunk, level, is_last, strategy=strategy)
+    buf = d + chunk
+    cap = len(buf) + 512
+    out = C.create_string_buffer(cap)
+    n = lib().ora_deflate_chunk_d(buf, len(buf), len(d), level, strategy, 0, int(is_last), out, cap, None, None)
+    if n == 0:
+        raise RuntimeError("oracle deflate_chunk_d failed")
     return out.raw[:n]
 
 

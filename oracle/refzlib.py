@@ -181,6 +181,26 @@ def deflate_chunk_raw(chunk: bytes, level: int, is_last: bool, pos0_matchable: b
     return out.raw[:n]
 
 
+def deflate_chunk_dict_raw(dictionary: bytes, chunk: bytes, level: int, is_last: bool, strategy: int = 0) -> bytes:
+    """F with a preset dictionary, by the reference: fresh raw stream, deflateSetDictionary, the chunk, Z_FINISH / Z_FULL_FLUSH."""
+    L = lib()
+    s = ZStream()
+    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, -15, 8, strategy, b"1.2.3", C.sizeof(ZStream))
+    assert rc == Z_OK, rc
+    rc = L.deflateSetDictionary(C.byref(s), dictionary, len(dictionary))
+    assert rc == Z_OK, rc
+    cap = len(chunk) + (len(chunk) >> 8) + 256
+    out = C.create_string_buffer(cap)
+    inb = C.create_string_buffer(chunk, max(len(chunk), 1))
+    s.next_in = C.addressof(inb); s.avail_in = len(chunk)
+    s.next_out = C.addressof(out); s.avail_out = cap
+    rc = L.deflate(C.byref(s), Z_FINISH if is_last else Z_FULL_FLUSH)
+    assert rc == (Z_STREAM_END if is_last else Z_OK) and s.avail_in == 0, rc
+    n = s.total_out
+    L.deflateEnd(C.byref(s))
+    return out.raw[:n]
+
+
 def zlib_header(level: int) -> bytes:
     """2-byte zlib header for windowBits=15, no dictionary (reference deflate.c:625-641)."""
     hdr = (Z_DEFLATED + ((15 - 8) << 4)) << 8
