@@ -118,6 +118,14 @@ int zgpu_deflate_segments_host(zgpu_engine *e, const void *in, const uint64_t *s
                                const zgpu_deflate_params *p, void *out, uint64_t out_cap, uint64_t *out_offsets,
                                zgpu_deflate_result *res);
 
+/* One chunk with a preset dictionary (deflateSetDictionary, qcsrc/deflate.c:315-354).  `window` holds the dictionary bytes the
+ * reference copies into its window -- the last min(length, 32506) bytes of the dictionary, at least 3 -- followed by the data;
+ * window_bytes <= 65536.  Output: the raw deflate stream of the data alone, exactly what the reference's fresh stream emits
+ * after deflateSetDictionary when it is finished (ZGPU_F_FINAL) or full-flushed; ZGPU_F_CRC32 as usual.  result.adler32 /
+ * crc32 / data_type describe the data alone.  (One lane works on one chunk here: meant for the first chunk of a stream.) */
+int zgpu_deflate_dict_chunk_host(zgpu_engine *e, const void *window, uint32_t window_bytes, uint32_t dict_bytes,
+                                 const zgpu_deflate_params *p, void *out, uint64_t out_cap, zgpu_deflate_result *res);
+
 /* ---- inflate ---- */
 /* Segment k = d_in[offsets[k] .. offsets[k+1]) is a raw-deflate segment that decodes to at most
  * chunk_size bytes, written at d_out + k*chunk_size (every segment but the last must decode to exactly

@@ -160,7 +160,7 @@ static void zlib_header(int level, int strategy, uint8_t hdr[2]) // qcsrc/deflat
 // d_seg (optional): device table of nseg+1 offsets; then every segment is one chunk and chunk_size is ignored.
 static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_seg, uint64_t nseg,
                           const zgpu_deflate_params *p, uint8_t *d_out, uint64_t out_cap, uint64_t *d_chunk_offsets,
-                          zgpu_deflate_result *res, hipStream_t st)
+                          zgpu_deflate_result *res, hipStream_t st, uint32_t skip0 = 0)
 {
     if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
@@ -182,6 +182,11 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
+    if (skip0) { // a preset dictionary in front of the one chunk: the lane-per-chunk loop is the implementation that starts mid-window
+        if (d_seg || in_bytes > kChunkMax || skip0 < kMinMatch || skip0 > kMaxDist || skip0 > in_bytes || (p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP | ZGPU_F_POS0 | ZGPU_F_POS0_ALL)))
+            return fail(e, ZGPU_STREAM_ERROR, "dictionary chunk: 3..32506 dictionary bytes + data <= 65536, no wrapper");
+        impl = ZGPU_LZ_SERIAL;
+    }
     const bool serial = impl == ZGPU_LZ_SERIAL;
     if (d_seg && ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
@@ -210,6 +215,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     g.final_chunk = (!d_seg && (p->flags & ZGPU_F_FINAL)) ? nchunks - 1 : ~0ull;
     g.all_final = (d_seg && (p->flags & ZGPU_F_FINAL)) ? 1u : 0u;
     g.pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
+    g.skip0 = skip0;
     const uint64_t body_cap = tail_bytes ? (out_cap >= head_bytes + tail_bytes ? out_cap - tail_bytes : 0) : out_cap;
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
@@ -254,7 +260,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     collect_spans(e);
     if (sort_fault) { // the LDS did not serve an atomic's lanes in lane order: redo the call with the sort that does not rely on it
         e->exact_sort = 1;
-        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st);
+        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st, skip0);
     }
     if (rs.overflow || (tail_bytes && out_cap < rs.out_total + tail_bytes)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
@@ -356,6 +362,25 @@ int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, con
     if (!e) return ZGPU_STREAM_ERROR;
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
     return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, nullptr, 0, p, static_cast<uint8_t *>(d_out), out_cap, d_chunk_offsets, res, st);
+}
+
+int zgpu_deflate_dict_chunk_host(zgpu_engine *e, const void *window, uint32_t window_bytes, uint32_t dict_bytes, const zgpu_deflate_params *p,
+                                 void *out, uint64_t out_cap, zgpu_deflate_result *res)
+{
+    if (!e || !p || !res || !window || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    const uint64_t bound = zgpu_deflate_bound(window_bytes, kChunkMax);
+    int rc = ensure_stage(e, window_bytes, bound);
+    if (rc) return rc;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, window, window_bytes, hipMemcpyHostToDevice, e->stream));
+    zgpu_deflate_params q = *p;
+    q.chunk_size = kChunkMax;
+    rc = deflate_device(e, e->stage_in, window_bytes, nullptr, 0, &q, e->stage_out, bound, nullptr, res, e->stream, dict_bytes);
+    if (rc) return rc;
+    if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return ZGPU_OK;
 }
 
 int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out, uint64_t out_cap,

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     const uint32_t ntok = meta[c].ntok, nostore = meta[c].nostore;
     const bool final_chunk_here = chunk_is_final(g, c);
     const uint32_t nblocks = ntok / kBlockTokens + 1;
-    uint32_t block_start = 0, data_type = 2;
+    uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
     if (tid == 0) sh_bitpos = 0;
 
     for (uint32_t b = 0; b < nblocks; b++) {

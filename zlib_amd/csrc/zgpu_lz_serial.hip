@@ -22,7 +22,7 @@ struct __attribute__((packed, aligned(1))) U64s { uint64_t v; };
 
 struct SerialLz {
     const uint8_t *__restrict__ in;
-    uint32_t n, base, off;
+    uint32_t n, base, off, start; // start: a preset dictionary occupies positions [0, start) (deflate.c:315-354)
     uint16_t *head, *prev;
     uint32_t *tok;
     uint32_t ntok, blk_tok0, nblk, nostore, block_start;
@@ -104,8 +104,9 @@ __device__ void lz_serial_chunk(SerialLz &s)
 {
     const uint32_t n = s.n;
     uint32_t room = 2 * kWSize - s.base, buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
-    uint32_t p = 0, match_len = kMinMatch - 1, prev_len = 0, mstart = 0, prev_match = 0, hh = 0;
+    uint32_t p = s.start, match_len = kMinMatch - 1, prev_len = 0, mstart = 0, prev_match = 0, hh = 0;
     bool pending = false;
+    for (uint32_t q = 0; q + kMinMatch <= s.start; q++) s.insert(q); // all dictionary strings but the last two (deflate.c:345-351)
     for (;;) {
         if (buffered - p < kMinLookahead) { s.refill(p); buffered = n; if (n == p) break; }
         uint32_t look = n - p;
@@ -163,10 +164,10 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
     chunk_span(g, c, lo, n);
     SerialLz s;
     s.in = g.in + lo; s.n = n;
-    s.base = chunk_base(g, c); s.off = 0;
+    s.base = chunk_base(g, c); s.off = 0; s.start = chunk_skip(g, c);
     s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
     s.tok = tokens + (size_t)c * kChunkMax;
-    s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = 0; s.cfg = cfg;
+    s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
     if (cfg.slow) lz_serial_chunk<true>(s); else lz_serial_chunk<false>(s);
     meta[c].ntok = s.ntok; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
 }

@@ -30,7 +30,9 @@ __global__ void __launch_bounds__(256) adler_kernel(ChunkGeom g, ChunkMeta *meta
     if (c >= g.nchunks) return;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
-    const uint8_t *src = g.in + lo;
+    const uint32_t skip = chunk_skip(g, c); // a preset dictionary in front of the data is not part of the checksum
+    const uint8_t *src = g.in + lo + skip;
+    n -= skip;
     uint32_t s1 = 0; uint64_t s2 = 0;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const uint4 *v = reinterpret_cast<const uint4 *>(src);
@@ -97,7 +99,9 @@ __global__ void __launch_bounds__(256) crc_kernel(ChunkGeom g, ChunkMeta *meta)
     if (c >= g.nchunks) return;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
-    const uint8_t *src = g.in + lo;
+    const uint32_t skip = chunk_skip(g, c);
+    const uint8_t *src = g.in + lo + skip;
+    n -= skip;
     {
         uint32_t r = tid;
 #pragma unroll

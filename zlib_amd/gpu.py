@@ -74,6 +74,7 @@ def load_library():
     L.zgpu_inflate_message.restype = C.c_char_p
     L.zgpu_adler32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
     L.zgpu_crc32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
+    L.zgpu_deflate_dict_chunk_host.argtypes = [vp, vp, u32, u32, vp, vp, u64, vp]
     L.zgpu_profile_enable.argtypes = [vp, C.c_int]
     L.zgpu_profile_enable.restype = None
     L.zgpu_profile_reset.argtypes = [vp]
@@ -111,6 +112,20 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise EngineError(rc, self.L.zgpu_engine_error(self.h).decode())
+
+    def deflate_dict_chunk_host(self, dictionary, chunk, level, final, strategy=0, flags=0):
+        """One chunk behind a preset dictionary (its last 32506 bytes count); returns the raw deflate stream of `chunk`."""
+        import numpy as np
+        d = bytes(dictionary)[-32506:]
+        buf = np.frombuffer(d + bytes(chunk) + b"\0", dtype=np.uint8)
+        n = len(d) + len(chunk)
+        cap = self.L.zgpu_deflate_bound(n, CHUNK)
+        out = np.empty(cap, dtype=np.uint8)
+        p = _Params(level, CHUNK, flags | (F_FINAL if final else 0), LZ_AUTO, strategy, 0)
+        res = DeflateResult()
+        self._check(self.L.zgpu_deflate_dict_chunk_host(self.h, buf.ctypes.data, n, len(d), C.byref(p), out.ctypes.data, cap, C.byref(res)))
+        self.last = res
+        return out[: res.out_bytes].tobytes()
 
     # ---- deflate ----
     def deflate_host(self, data, level, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO, want_offsets=False, strategy=0):
