@@ -147,6 +147,9 @@ int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_by
 int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap,
                              zgpu_inflate_result *res);
 const char *zgpu_inflate_message(uint32_t index);
+/* Preset dictionary of the inflate calls that follow (inflateSetDictionary, qcsrc/inflate.c:1200-1236): the first segment of a
+ * call may reach back into its last min(len, 32768) bytes.  Stays set until replaced; len 0 clears it. */
+int zgpu_inflate_set_dictionary(zgpu_engine *e, const void *dict, uint32_t len);
 
 /* ---- checksums (qcsrc/adler32.c:57-149) ---- */
 int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream);

@@ -13,8 +13,9 @@
  *     unchunked output, whose matches cross 64 KiB boundaries.
  *   - Served parameters: method Z_DEFLATED, windowBits 15 (zlib wrapper), -15 (raw) or 31 (gzip wrapper with the
  *     default header; inflate also 47 = zlib or gzip, detected), memLevel 8, all five strategies, levels 0..9 and
- *     Z_DEFAULT_COMPRESSION, deflateParams.  Anything else returns Z_STREAM_ERROR (preset dictionaries,
- *     deflateSetHeader / inflateGetHeader, deflateTune/Prime/Copy are "next" rows of SURVEY.md 8f).
+ *     Z_DEFAULT_COMPRESSION, deflateParams, preset dictionaries (set before the first input byte).  Anything else
+ *     returns Z_STREAM_ERROR (deflateSetHeader / inflateGetHeader, deflateTune/Prime/Copy are "next" rows of
+ *     SURVEY.md 8f).
  *   - There is no CPU codec behind this API: without a usable GPU, the Init functions return Z_MEM_ERROR with
  *     strm->msg explaining why.
  */
@@ -104,7 +105,7 @@ int deflate(z_streamp strm, int flush);
 int deflateEnd(z_streamp strm);
 int deflateReset(z_streamp strm);
 uLong deflateBound(z_streamp strm, uLong sourceLen);
-int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength); /* Z_STREAM_ERROR: not served */
+int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength); /* before the first input byte */
 int deflateParams(z_streamp strm, int level, int strategy);
 
 int inflateInit_(z_streamp strm, const char *version, int stream_size);
@@ -112,7 +113,7 @@ int inflateInit2_(z_streamp strm, int windowBits, const char *version, int strea
 int inflate(z_streamp strm, int flush);
 int inflateEnd(z_streamp strm);
 int inflateReset(z_streamp strm);
-int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength); /* Z_STREAM_ERROR: not served */
+int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength);
 
 int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);
 int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level);

@@ -152,3 +152,19 @@ def test_foreign_single_segment_stream():
     assert rc == 0
     rc, back = Z.uncompress(z, len(tricky))
     assert rc == 0 and back == tricky
+
+
+def test_level0_block_structure():
+    """deflate_stored's cuts (deflate.c:1390-1439) for chunk lengths around MAX_DIST and the 65531-byte block limit, finished or
+    flushed: the host library's framing against the oracle (which is pinned to the reference for level 0)."""
+    from oracle import cases, oracle_py as O
+    for n in (0, 1, 1000, 32505, 32506, 32507, 40000, 65531, 65532, 65535, 65536, 65536 + 32506, 2 * 65536 + 40000):
+        data = cases.make("text", n, 3)
+        z, codes, info = Z.deflate_stream(data, 0, [(n, Z.Z_FINISH)])
+        assert z == O.deflate_stream(data, 0), n
+        if n:
+            z2, codes, info = Z.deflate_stream(data, 0, [(n, Z.Z_FULL_FLUSH), (0, Z.Z_FINISH)])
+            nch = (n + 65535) // 65536
+            want = O.deflate_stream(b"", 0)[:2] + b"".join(O.deflate_chunk(data[k * 65536:(k + 1) * 65536], 0, False) for k in range(nch)) + \
+                O.deflate_chunk(b"", 0, True) + O.adler32(data).to_bytes(4, "big")
+            assert z2 == want, n

@@ -58,6 +58,7 @@ struct zgpu_engine {
     zgpu::ChunkMeta *inf_meta = nullptr; uint32_t inf_meta_cap = 0;
     uint64_t *inf_offs = nullptr; uint64_t inf_offs_cap = 0;
     void *inf_slots = nullptr; uint64_t inf_slots_cap = 0;
+    uint8_t *inf_dict = nullptr; uint32_t inf_dict_len = 0; // preset dictionary of the next inflate calls (zgpu_inflate_set_dictionary)
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -341,7 +342,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
-    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots);
+    hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     hipStreamDestroy(e->stream);
     delete e;
@@ -466,6 +467,17 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
     return ZGPU_OK;
 }
 
+int zgpu_inflate_set_dictionary(zgpu_engine *e, const void *dict, uint32_t len)
+{
+    if (!e || (!dict && len)) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    if (len > kWSize) { dict = static_cast<const uint8_t *>(dict) + (len - kWSize); len = kWSize; } // the window keeps the tail (inflate.c:1222-1226)
+    if (len && !e->inf_dict) ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&e->inf_dict), kWSize));
+    if (len) { ZGPU_HIP_CHECK(hipMemcpyAsync(e->inf_dict, dict, len, hipMemcpyHostToDevice, e->stream)); ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream)); }
+    e->inf_dict_len = len;
+    return ZGPU_OK;
+}
+
 int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream)
 {
     if (!e || !adler_out || (!d_in && in_bytes)) return fail(e, ZGPU_STREAM_ERROR, "null argument");
@@ -576,6 +588,8 @@ void *engine_scratch2(zgpu_engine *e, size_t bytes)
 void *engine_run_state(zgpu_engine *e) { return e->run; }
 uint8_t *engine_stage_in(zgpu_engine *e) { return e->stage_in; }
 uint8_t *engine_stage_out(zgpu_engine *e) { return e->stage_out; }
+const uint8_t *engine_inflate_dict(zgpu_engine *e) { return e->inf_dict; }
+uint32_t engine_inflate_dict_len(zgpu_engine *e) { return e->inf_dict_len; }
 int engine_ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes) { return ensure_stage(e, in_bytes, out_bytes); }
 hipStream_t engine_stream(zgpu_engine *e) { return e->stream; }
 ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch)

@@ -24,6 +24,8 @@ namespace zgpu {
 int fail_hip(zgpu_engine *e, hipError_t err, const char *what, const char *file, int line);
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
+const uint8_t *engine_inflate_dict(zgpu_engine *e);
+uint32_t engine_inflate_dict_len(zgpu_engine *e);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st, bool with_crc = false);
@@ -199,7 +201,8 @@ __device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t t
 
 __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
                                                      uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
-                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta)
+                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
+                                                     const uint8_t *__restrict__ dict, uint32_t dict_len)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
@@ -229,6 +232,11 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     drop(b, lead * 8);
 
     uint32_t o = 0;       // bytes produced
+    // a preset dictionary (inflateSetDictionary, inflate.c:1200-1236) is what the window holds before the first byte: in the ring it
+    // sits right below position 0, and the first segment may reach that much farther back
+    const uint32_t reach = (gc == 0) ? dict_len : 0u;
+    for (uint32_t i = lane; i < reach; i += 64) L.out[(kOutRing - reach + i) & (kOutRing - 1)] = dict[i];
+    __syncthreads();
     uint32_t flushed = 0; // bytes already copied from the LDS ring to the destination (a multiple of kOutHalf until the end)
     bool nofit = false;   // direct placement: the destination ended before the chunk did
     uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             if (ed & kEntBad) { err = kMsgDistCode; break; }
             const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
             drop(b, xd);
-            if (dist > o) { err = kMsgTooFar; break; }
+            if (dist > o + reach) { err = kMsgTooFar; break; }
             if (o + len > chunk_size) { err = kMsgOutput; break; }
             // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259).
             // The ring holds the last 32 KiB: a read at the full distance 32768 hits the slot its own lane is about to write.
@@ -502,7 +510,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
         hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(64), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
-                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr);
+                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e));
         hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc);
         if (compact) {
             launch_scan(meta, nb, c0, oscr, engine_run_state(e), out_cap, st); // out_bytes -> byte offsets, continuing across batches

@@ -75,6 +75,7 @@ def load_library():
     L.zgpu_adler32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
     L.zgpu_crc32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
     L.zgpu_deflate_dict_chunk_host.argtypes = [vp, vp, u32, u32, vp, vp, u64, vp]
+    L.zgpu_inflate_set_dictionary.argtypes = [vp, vp, u32]
     L.zgpu_profile_enable.argtypes = [vp, C.c_int]
     L.zgpu_profile_enable.restype = None
     L.zgpu_profile_reset.argtypes = [vp]
@@ -112,6 +113,10 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise EngineError(rc, self.L.zgpu_engine_error(self.h).decode())
+
+    def inflate_set_dictionary(self, dictionary):
+        d = bytes(dictionary) if dictionary else b""
+        self._check(self.L.zgpu_inflate_set_dictionary(self.h, d if d else None, len(d)))
 
     def deflate_dict_chunk_host(self, dictionary, chunk, level, final, strategy=0, flags=0):
         """One chunk behind a preset dictionary (its last 32506 bytes count); returns the raw deflate stream of `chunk`."""

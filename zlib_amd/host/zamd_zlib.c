@@ -157,6 +157,10 @@ struct internal_state {
     uint32_t crc;     /* the same for CRC-32 (gzip wrapper, wrap == 2) */
     int decoded;      /* inflate: the body has been decoded */
     size_t next_try;  /* inflate: do not re-try a decode before this many bytes have been collected */
+    bytebuf dict;     /* preset dictionary: deflate, the bytes the window receives until the first chunk is out; inflate, as set */
+    int dict_pending; /* deflate: the first chunk has not been compressed yet and starts behind the dictionary */
+    int need_dict, have_dict; /* inflate: the header asked for one / one has been set */
+    uint32_t dictid;  /* Adler-32 of the dictionary (header field, deflate.c:646-649, inflate.c:623-627) */
 };
 
 static uLong bound_for(uLong n)
@@ -186,7 +190,7 @@ static struct internal_state *state_new(z_streamp strm, int kind)
 static void state_free(z_streamp strm)
 {
     struct internal_state *s = strm->state;
-    free(s->in.p); free(s->out.p);
+    free(s->in.p); free(s->out.p); free(s->dict.p);
     strm->zfree(strm->opaque, s);
     strm->state = Z_NULL;
 }
@@ -231,7 +235,7 @@ EXPORT int deflateReset(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->data_type = Z_UNKNOWN;
-    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0;
+    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0; s->dict.len = 0; s->dict_pending = 0;
     s->status = s->wrap ? ST_INIT : ST_BUSY; s->last_flush = Z_NO_FLUSH;
     s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
     return Z_OK;
@@ -243,7 +247,20 @@ EXPORT int deflateEnd(z_streamp strm)
     state_free(strm);
     return busy ? Z_DATA_ERROR : Z_OK; /* deflate.c:886 */
 }
-EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n) { (void)strm; (void)d; (void)n; return Z_STREAM_ERROR; }
+/* deflate.c:315-354.  Served before the first byte of input (the reference also lets a raw stream replace its window later). */
+EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE || d == Z_NULL) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || s->any_block || s->in.len != 0 || strm->total_in != 0) return Z_STREAM_ERROR;
+    if (s->wrap) strm->adler = adler32(strm->adler, d, n); /* becomes the DICTID of the header */
+    if (n < 3) return Z_OK;                                /* shorter than MIN_MATCH: nothing to match against */
+    const uInt keep = n > 32506u ? 32506u : n;            /* MAX_DIST: the tail of the dictionary */
+    s->dict.len = 0;
+    if (!buf_put(&s->dict, d + (n - keep), keep)) return Z_MEM_ERROR;
+    s->dict_pending = 1;
+    return Z_OK;
+}
 static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final);
 /* deflate.c:416-451.  What was handed to deflate() so far is compressed with the old parameters (as one more run of chunks,
  * ending in a flush marker), what follows with the new ones. */
@@ -265,20 +282,26 @@ EXPORT int deflateParams(z_streamp strm, int level, int strategy)
 /* level 0 needs no match finder or entropy coder: stored blocks are framing.  One chunk = the bytes the reference's
  * deflate_stored emits for a fresh stream of that chunk (deflate.c:1390-1439): blocks of at most 65531 bytes, the rest,
  * then the flush marker or, on the last chunk, the final bit. */
+static int stored_block(bytebuf *out, const uint8_t *src, size_t len, int last)
+{
+    const uint8_t h[5] = {(uint8_t)(last ? 1 : 0), (uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
+    return buf_put(out, h, 5) && buf_put(out, src, len);
+}
 static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final)
 {
     size_t nchunks = n ? (n + CHUNK - 1) / CHUNK : 1;
     for (size_t k = 0; k < nchunks; k++) {
-        size_t lo = k * CHUNK, len = n - lo < CHUNK ? n - lo : CHUNK, done = 0;
-        int last_chunk = final && k + 1 == nchunks;
-        do {
-            size_t piece = len - done > 65531 ? 65531 : len - done;
-            int last_piece = done + piece == len;
-            uint8_t h[5] = {(uint8_t)(last_piece && last_chunk ? 1 : 0), (uint8_t)piece, (uint8_t)(piece >> 8), (uint8_t)~piece, (uint8_t)(~piece >> 8)};
-            if (!buf_put(out, h, 5) || !buf_put(out, src + lo + done, piece)) return 0;
-            done += piece;
-        } while (done < len);
-        if (!last_chunk) { static const uint8_t marker[5] = {0, 0, 0, 0xff, 0xff}; if (!buf_put(out, marker, 5)) return 0; }
+        const size_t lo = k * CHUNK, len = n - lo < CHUNK ? n - lo : CHUNK;
+        const int last = final && k + 1 == nchunks;
+        int ok;
+        /* what deflate_stored emits for a fresh stream of `len` bytes: a block is cut at 65531 bytes (pending_buf_size - 5,
+         * deflate.c:1397-1402,1420-1427) or as soon as it reaches MAX_DIST = 32506 bytes (:1431-1434), and the flush at the end
+         * then closes whatever is left -- an EMPTY block after a MAX_DIST cut that took everything */
+        if (len > 65531) ok = stored_block(out, src + lo, 65531, 0) && stored_block(out, src + lo + 65531, len - 65531, last);
+        else if (len >= 32506) ok = stored_block(out, src + lo, len, 0) && stored_block(out, src + lo, 0, last);
+        else ok = stored_block(out, src + lo, len, last);
+        if (!ok) return 0;
+        if (!last) { static const uint8_t marker[5] = {0, 0, 0, 0xff, 0xff}; if (!buf_put(out, marker, 5)) return 0; }
     }
     return 1;
 }
@@ -287,6 +310,39 @@ static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final)
 static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
 {
     struct internal_state *s = strm->state;
+    if (s->dict_pending) {
+        /* The first chunk shares the 64 KiB window with the dictionary: it takes 65536 - |dictionary| bytes (or all there is) and
+         * goes through the engine's dictionary entry point; whatever follows is ordinary chunks.  Stored blocks (level 0) come out
+         * the same with or without a dictionary. */
+        const size_t room = CHUNK - s->dict.len, take = n < room ? n : room;
+        const int first_final = final && take == n;
+        s->dict_pending = 0;
+        if (s->level == 0) {
+            if (!stored_chunks(&s->out, src, take, first_final)) return Z_MEM_ERROR;
+            s->adler = (uint32_t)adler32(s->adler, src, (uInt)take);
+        } else {
+            zgpu_engine *e = engine_get();
+            if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
+            bytebuf w = {0};
+            if (!buf_put(&w, s->dict.p, s->dict.len) || !buf_put(&w, src, take)) { free(w.p); return Z_MEM_ERROR; }
+            const uint64_t cap = zgpu_deflate_bound(w.len, CHUNK);
+            if (!buf_reserve(&s->out, cap)) { free(w.p); return Z_MEM_ERROR; }
+            zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, 0};
+            zgpu_deflate_result r;
+            pthread_mutex_lock(&g_lock);
+            int rc = zgpu_deflate_dict_chunk_host(e, w.p, (uint32_t)w.len, (uint32_t)s->dict.len, &p, s->out.p + s->out.len, cap, &r);
+            pthread_mutex_unlock(&g_lock);
+            free(w.p);
+            if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
+            s->out.len += r.out_bytes;
+            s->adler = adler_join(s->adler, r.adler32, take);
+            if (take > 0) strm->data_type = (int)r.data_type;
+        }
+        s->any_block = 1;
+        s->dict.len = 0;
+        if (take == n) return Z_OK;
+        src += take; n -= take;
+    }
     if (s->level == 0) {
         if (!stored_chunks(&s->out, src, n, final)) return Z_MEM_ERROR;
         for (size_t o = 0; o < n; o += 0x40000000u) {
@@ -331,9 +387,12 @@ EXPORT int deflate(z_streamp strm, int flush)
     }
     if (s->status == ST_INIT) { /* zlib header, deflate.c:625-649 */
         unsigned hdr = (Z_DEFLATED + (7u << 4)) << 8, lf = (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
-        hdr |= lf << 6; hdr += 31 - hdr % 31;
-        uint8_t h[2] = {(uint8_t)(hdr >> 8), (uint8_t)hdr};
-        if (!buf_put(&s->out, h, 2)) return Z_MEM_ERROR;
+        hdr |= lf << 6;
+        if (s->dict_pending) hdr |= 0x20; /* PRESET_DICT, deflate.c:641 */
+        hdr += 31 - hdr % 31;
+        uint8_t h[6] = {(uint8_t)(hdr >> 8), (uint8_t)hdr, (uint8_t)(strm->adler >> 24), (uint8_t)(strm->adler >> 16), (uint8_t)(strm->adler >> 8), (uint8_t)strm->adler};
+        if (!buf_put(&s->out, h, s->dict_pending ? 6 : 2)) return Z_MEM_ERROR;
+        strm->adler = 1; /* deflate.c:650 */
         s->status = ST_BUSY;
     }
     if (s->out.len - s->out_pos != 0) { /* deflate.c:757-768 */
@@ -349,7 +408,20 @@ EXPORT int deflate(z_streamp strm, int flush)
         const uint8_t *src = strm->next_in; size_t n = strm->avail_in;
         strm->next_in += n; strm->total_in += n; strm->avail_in = 0;
         int rc = Z_OK;
-        if (flush == Z_NO_FLUSH) {
+        if (flush == Z_NO_FLUSH && s->dict_pending) {
+            /* the first chunk behind a dictionary is 65536 - |dictionary| bytes: collect until it is complete */
+            const size_t room = CHUNK - s->dict.len;
+            if (!buf_put(&s->in, src, n)) rc = Z_MEM_ERROR;
+            else if (s->in.len >= room) {
+                rc = run_chunks(strm, s->in.p, room, 0);
+                memmove(s->in.p, s->in.p + room, s->in.len - room); s->in.len -= room;
+                if (rc == Z_OK && s->in.len >= CHUNK) {
+                    size_t whole = s->in.len - s->in.len % CHUNK;
+                    rc = run_chunks(strm, s->in.p, whole, 0);
+                    memmove(s->in.p, s->in.p + whole, s->in.len - whole); s->in.len -= whole;
+                }
+            }
+        } else if (flush == Z_NO_FLUSH) {
             /* only complete chunks are compressed now; the tail waits for more input */
             if (s->in.len == 0 && n >= CHUNK) { size_t whole = n - n % CHUNK; rc = run_chunks(strm, src, whole, 0); src += whole; n -= whole; }
             if (rc == Z_OK && n) { if (!buf_put(&s->in, src, n)) rc = Z_MEM_ERROR; }
@@ -414,7 +486,7 @@ EXPORT int inflateReset(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->adler = 1;
-    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->decoded = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0;
+    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->decoded = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0; s->dict.len = 0; s->need_dict = 0; s->have_dict = 0;
     return Z_OK;
 }
 EXPORT int inflateEnd(z_streamp strm)
@@ -423,7 +495,19 @@ EXPORT int inflateEnd(z_streamp strm)
     state_free(strm);
     return Z_OK;
 }
-EXPORT int inflateSetDictionary(z_streamp strm, const Bytef *d, uInt n) { (void)strm; (void)d; (void)n; return Z_STREAM_ERROR; }
+/* inflate.c:1200-1236 */
+EXPORT int inflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE || d == Z_NULL) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (s->wrap != 0 && !s->need_dict) return Z_STREAM_ERROR;
+    if (s->need_dict && (uint32_t)adler32(1, d, n) != s->dictid) return Z_DATA_ERROR;
+    const uInt keep = n > 32768u ? 32768u : n; /* the window keeps the tail */
+    s->dict.len = 0;
+    if (keep && !buf_put(&s->dict, d + (n - keep), keep)) return Z_MEM_ERROR;
+    s->have_dict = 1; s->need_dict = 0;
+    return Z_OK;
+}
 
 /* Decode everything collected in s->in.  Returns Z_OK when decoded, Z_BUF_ERROR when the stream is visibly incomplete,
  * Z_DATA_ERROR / Z_MEM_ERROR otherwise.  out_hint: how much room the caller said it has (sizes the first attempt). */
@@ -454,8 +538,13 @@ static int decode_all(z_streamp strm, size_t out_hint)
         if (!(s->wrap & 1) || (((unsigned)p[0] << 8) + p[1]) % 31) { strm->msg = (char *)"incorrect header check"; return Z_DATA_ERROR; }
         if ((p[0] & 15) != Z_DEFLATED) { strm->msg = (char *)"unknown compression method"; return Z_DATA_ERROR; }
         if ((unsigned)(p[0] >> 4) + 8 > (unsigned)s->level) { strm->msg = (char *)"invalid window size"; return Z_DATA_ERROR; }
-        if (p[1] & 0x20) return Z_NEED_DICT;
         skip = 2;
+        if (p[1] & 0x20) { /* DICTID follows the header, inflate.c:617-627 */
+            if (n < 6) return Z_BUF_ERROR;
+            s->dictid = ((uint32_t)p[2] << 24) | ((uint32_t)p[3] << 16) | ((uint32_t)p[4] << 8) | p[5];
+            if (!s->have_dict) { strm->adler = s->dictid; s->need_dict = 1; return Z_NEED_DICT; }
+            skip = 6;
+        }
         if (n < skip + 4 + 2) return Z_BUF_ERROR;
     }
     const size_t tail = gz ? 8 : s->wrap ? 4 : 0;
@@ -470,7 +559,9 @@ static int decode_all(z_streamp strm, size_t out_hint)
         if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
         zgpu_inflate_result r;
         pthread_mutex_lock(&g_lock);
-        int rc = zgpu_inflate_stream_host(e, p + skip, body, s->out.p, cap, &r);
+        int rc = zgpu_inflate_set_dictionary(e, s->have_dict ? s->dict.p : NULL, s->have_dict ? (uint32_t)s->dict.len : 0u);
+        if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host(e, p + skip, body, s->out.p, cap, &r);
+        if (s->have_dict) zgpu_inflate_set_dictionary(e, NULL, 0);
         pthread_mutex_unlock(&g_lock);
         if (rc == ZGPU_BUF_ERROR) { cap *= 4; if (cap > ((size_t)1 << 40)) return Z_MEM_ERROR; continue; }
         if (rc == ZGPU_DATA_ERROR) {
