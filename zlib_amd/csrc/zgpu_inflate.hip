@@ -84,7 +84,7 @@ __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_r
 __device__ inline void settle(BitSrc &b) // (the compiler cannot see that loop-carried reader state is wave-uniform: tell it once per symbol)
 {
     b.hold = (uint64_t)uni((uint32_t)b.hold) | ((uint64_t)uni((uint32_t)(b.hold >> 32)) << 32);
-    b.bits = uni(b.bits); b.rd = uni(b.rd); b.filled = uni(b.filled);
+    b.bits = uni(b.bits); b.rd = uni(b.rd); b.filled = uni(b.filled); b.seg_bits = uni(b.seg_bits);
 }
 
 __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
