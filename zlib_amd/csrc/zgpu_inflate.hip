@@ -79,6 +79,22 @@ struct BitSrc {
 
 // The bit reader's state is the same in all lanes; values that come back from LDS are declared so (v_readfirstlane), which
 // moves the whole decode loop -- shifts, masks, compares, branches -- from the vector pipe to scalar instructions.
+#ifdef ZGPU_INF_TIME // debug build only (scripts/inf_time.py): clock per phase, summed over chunks
+__device__ unsigned long long inf_time[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_inf_time(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(inf_time), sizeof z);
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(inf_time), z, sizeof z);
+}
+#define INF_T(i) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&inf_time[i], t_ - t_prev); t_prev = wall_clock64(); } while (0)
+#define INF_T0() unsigned long long t_prev = wall_clock64(); unsigned long long n_lit = 0, n_mat = 0, n_slow = 0
+#define INF_N(x) x++
+#else
+#define INF_T(i) do { } while (0)
+#define INF_T0() do { } while (0)
+#define INF_N(x) do { } while (0)
+#endif
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ inline void settle(BitSrc &b) // (the compiler cannot see that loop-carried reader state is wave-uniform: tell it once per symbol)
@@ -215,6 +231,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     const bool compact = chunk_size_arg == 0;
     const uint32_t chunk_size = compact ? kChunkMax : chunk_size_arg;
     uint32_t err = kMsgNone;
+    INF_T0();
 
     BitSrc b;
     const uint64_t in_addr = reinterpret_cast<uint64_t>(in);
@@ -242,11 +259,32 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
     const uint64_t dst_room = compact ? kChunkMax : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
     // copy bytes [flushed, upto) of the output to the destination; the range never wraps in the ring
-    // a match's bytes are loaded when it is decoded and stored while the next symbol's table entry is on its way (commit)
-    uint32_t pend_addr = 0; uint8_t pend_v = 0; bool pend = false;
-    auto commit = [&]() { if (pend) { L.out[pend_addr] = pend_v; pend = false; } };
+    // copy a match of `len` bytes at distance `dist` to output position `at`; a distance shorter than the length repeats its
+    // pattern (byte-sequential semantics of inffast.c:246-259).  The ring holds the last 32 KiB: a read at the full distance
+    // 32768 hits the slot its own lane is about to write.
+    auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) {
+        __builtin_amdgcn_wave_barrier();
+        if (len <= 64 && dist >= len) { // the common case
+            if (lane < len) { const uint8_t v = L.out[(at - dist + lane) & (kOutRing - 1)]; L.out[(at + lane) & (kOutRing - 1)] = v; }
+        } else if (dist >= len || dist >= 64) {
+            for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
+                const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
+                uint8_t v = 0;
+                if (lane < span && i < len) v = L.out[(at - dist + i) & (kOutRing - 1)];
+                if (lane < span && i < len) L.out[(at + i) & (kOutRing - 1)] = v;
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            const uint32_t recip = 0xFFFFFFFFu / dist + 1;
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint32_t qd = dist == 1 ? i : __umulhi(i, recip), r = i - qd * dist; // recip overflows for dist 1
+                L.out[(at + i) & (kOutRing - 1)] = L.out[(at - dist + r) & (kOutRing - 1)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     auto flush_to = [&](uint32_t upto) {
-        commit();
+        INF_T(2);
         uint32_t nbytes = upto - flushed;
         if ((uint64_t)flushed + nbytes > dst_room) { nofit = true; nbytes = dst_room > flushed ? (uint32_t)(dst_room - flushed) : 0; }
         const uint8_t *src_r = L.out + (flushed & (kOutRing - 1));
@@ -259,10 +297,12 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             for (uint32_t i = lane; i < nbytes; i += 64) d[i] = src_r[i];
         }
         flushed = upto;
+        INF_T(3);
     };
     bool last = false, seen_final = false;
+    INF_T(0);
     while (!err && !last) {
-        commit();
+        INF_T(2);
         if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
         stage_fill(b, L.stage, lane); __syncthreads();
         refill(b, L.stage);
@@ -353,15 +393,67 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
         }
         __syncthreads();
+        INF_T(1);
         // ---- symbols ----
-        for (;;) {
-            settle(b);
-            o = uni(o); flushed = uni(flushed);
+        // Every lane decodes the token that would start at its own bit offset behind the reader (both table lookups, extra
+        // bits included); a scalar walk from offset 0 then picks the lanes that really are token starts (each token says
+        // where the next one begins) and hands out their output positions.  Literals are stored by their lanes at once,
+        // matches are copied one after the other.  A token the tables do not resolve (code longer than the table, end of
+        // block, invalid code, output limit, distance too far) ends the walk and goes through the one-symbol path below.
+        uint32_t pos = consumed_bits(b); // the reader's position in bits from the segment's origin dword
+        uint32_t how = 0;                // 1 end of block, 2 error
+        while (how == 0) {
+            pos = uni(pos); o = uni(o); flushed = uni(flushed);
+            b.rd = pos >> 5; b.filled = uni(b.filled);
             stage_fill(b, L.stage, lane);
-            refill(b, L.stage);
-            if (consumed_bits(b) > b.seg_bits) { err = kMsgTruncated; break; }
+            if (pos > b.seg_bits) { err = kMsgTruncated; break; }
+            uint32_t info; // bits 0-5 token length in bits, 6-7 kind (0 stop, 1 literal, 2 match), 8-16 bytes produced, 17-31 distance - 1
+            uint32_t lit_byte;
+            {
+                const uint32_t p = pos + lane, wi = p >> 5, sh = p & 31;
+                const uint32_t w0 = L.stage[wi & (kStageDwords - 1)], w1 = L.stage[(wi + 1) & (kStageDwords - 1)], w2 = L.stage[(wi + 2) & (kStageDwords - 1)];
+                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
+                const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
+                const uint32_t len = (e >> 16) + ((lo >> l1) & ((1u << xl) - 1));
+                const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
+                const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
+                const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
+                const uint32_t dist = (ed >> 16) + ((h2 >> l2) & ((1u << xd) - 1));
+                lit_byte = e >> 16;
+                const uint32_t as_match = (t + l2 + xd) | (2u << 6) | (len << 8) | ((dist - 1) << 17);
+                const bool match_ok = (e & kEntLen) && (ed & kEntLen);
+                info = (e & kEntLit) ? (l1 | (1u << 6) | (1u << 8)) : match_ok ? as_match : 0u;
+            }
+            uint32_t cur = 0, oc = o, offv = 0xFFFFFFFFu;
+            uint64_t mm = 0;
+            while (cur < 64) {
+                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur);
+                const uint32_t kind = (inf >> 6) & 3u, ol = (inf >> 8) & 511u;
+                if (kind == 0 || oc + ol > chunk_size) break;
+                if (kind == 2) { if ((inf >> 17) >= oc + reach) break; mm |= 1ull << cur; }
+                offv = lane == cur ? oc : offv;
+                oc += ol; cur += inf & 63u;
+            }
+            if (oc != o || cur != 0) {
+                if (offv != 0xFFFFFFFFu && (info & (1u << 6))) L.out[offv & (kOutRing - 1)] = (uint8_t)lit_byte;
+                INF_N(n_lit); // (rounds)
+                while (mm) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
+                    const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
+                    copy_match(mo, (inf >> 8) & 511u, (inf >> 17) + 1);
+                    INF_N(n_mat);
+                }
+                pos += cur; o = oc;
+                if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
+                continue;
+            }
+            // ---- one symbol through the scalar reader ----
+            INF_N(n_slow);
+            b.rd = pos >> 5; b.hold = 0; b.bits = 0;
+            prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
+            drop(b, pos & 31);
             uint32_t e = uni(L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)]);
-            commit();
             if (e) drop(b, e & 15u);
             else { // a code longer than the table, or no code at all
                 const uint32_t s2 = uni(decode_long(b.hold, L.lsym, L.lcount));
@@ -373,50 +465,36 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
                 if (o >= chunk_size) { err = kMsgOutput; break; }
                 L.out[o & (kOutRing - 1)] = (uint8_t)(e >> 16); // (every lane stores the same byte)
                 o++;
-                if (o == flushed + kOutHalf) flush_to(o);
-                continue;
-            }
-            if (e & kEntEob) break;
-            if (e & kEntBad) { err = kMsgLitCode; break; }
-            const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
-            drop(b, xl);
-            refill(b, L.stage);
-            uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
-            if (ed) drop(b, ed & 15u);
-            else {
-                const uint32_t d2 = uni(decode_long(b.hold, L.dsym, L.dcount));
-                if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
-                drop(b, d2 >> 16);
-                ed = make_entry(2, d2 & 0xFFFFu, 0);
-            }
-            if (ed & kEntBad) { err = kMsgDistCode; break; }
-            const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
-            drop(b, xd);
-            if (dist > o + reach) { err = kMsgTooFar; break; }
-            if (o + len > chunk_size) { err = kMsgOutput; break; }
-            // copy; a distance shorter than the length repeats its pattern (byte-sequential semantics of inffast.c:246-259).
-            // The ring holds the last 32 KiB: a read at the full distance 32768 hits the slot its own lane is about to write.
-            __builtin_amdgcn_wave_barrier();
-            if (len <= 64 && dist >= len) { // the common case: one load per lane now, the store later
-                if (lane < len) { pend_v = L.out[(o - dist + lane) & (kOutRing - 1)]; pend_addr = (o + lane) & (kOutRing - 1); pend = true; }
-            } else if (dist >= len || dist >= 64) {
-                for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
-                    const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
-                    uint8_t v = 0;
-                    if (lane < span && i < len) v = L.out[(o - dist + i) & (kOutRing - 1)];
-                    if (lane < span && i < len) L.out[(o + i) & (kOutRing - 1)] = v;
-                    __builtin_amdgcn_wave_barrier();
-                }
             } else {
-                const uint32_t recip = 0xFFFFFFFFu / dist + 1;
-                for (uint32_t i = lane; i < len; i += 64) {
-                    const uint32_t qd = dist == 1 ? i : __umulhi(i, recip), r = i - qd * dist; // recip overflows for dist 1
-                    L.out[(o + i) & (kOutRing - 1)] = L.out[(o - dist + r) & (kOutRing - 1)];
+                if (e & kEntEob) { how = 1; pos = consumed_bits(b); break; }
+                if (e & kEntBad) { err = kMsgLitCode; break; }
+                const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
+                drop(b, xl);
+                refill(b, L.stage);
+                uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
+                if (ed) drop(b, ed & 15u);
+                else {
+                    const uint32_t d2 = uni(decode_long(b.hold, L.dsym, L.dcount));
+                    if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
+                    drop(b, d2 >> 16);
+                    ed = make_entry(2, d2 & 0xFFFFu, 0);
                 }
-                __builtin_amdgcn_wave_barrier();
+                if (ed & kEntBad) { err = kMsgDistCode; break; }
+                const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
+                drop(b, xd);
+                if (dist > o + reach) { err = kMsgTooFar; break; }
+                if (o + len > chunk_size) { err = kMsgOutput; break; }
+                copy_match(o, len, dist);
+                o += len;
             }
-            o += len;
+            pos = consumed_bits(b);
             if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
+        }
+        // the scalar reader takes over again at the block boundary (or holds the position an error was found at)
+        if (how == 1 || err == kMsgTruncated) {
+            b.rd = pos >> 5; b.hold = 0; b.bits = 0;
+            prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
+            drop(b, pos & 31);
         }
     }
     // an error found in bits that lie past the end of the segment is the zero padding talking: the segment is truncated
@@ -432,14 +510,18 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
 #ifdef ZGPU_INF_DEBUG2
     if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
 #endif
-    commit();
+    INF_T(2);
     __syncthreads();
     // the rest of the chunk (an error leaves what was flushed before it was found; the status says the chunk is void)
     if (!err) flush_to(o);
     const bool fits = !nofit;
+    INF_T(4);
     if (lane == 0) {
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
+#ifdef ZGPU_INF_TIME
+        atomicAdd(&inf_time[5], n_lit); atomicAdd(&inf_time[6], n_mat); atomicAdd(&inf_time[7], n_slow);
+#endif
         if (meta) { meta[c].out_bytes = err ? 0 : o; meta[c].ntok = 0; meta[c].adler_a = 1; meta[c].adler_b = 0; meta[c].in_bytes = 0; meta[c].data_type = 2; }
     }
 }
