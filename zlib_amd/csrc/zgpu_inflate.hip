@@ -80,16 +80,24 @@ struct BitSrc {
 // The bit reader's state is the same in all lanes; values that come back from LDS are declared so (v_readfirstlane), which
 // moves the whole decode loop -- shifts, masks, compares, branches -- from the vector pipe to scalar instructions.
 #ifdef ZGPU_INF_TIME // debug build only (scripts/inf_time.py): clock per phase, summed over chunks
-__device__ unsigned long long inf_time[8];
+__device__ unsigned long long inf_time[16];
 extern "C" __attribute__((visibility("default"))) void zgpu_debug_inf_time(unsigned long long *out, int reset)
 {
-    unsigned long long z[8] = {};
+    unsigned long long z[16] = {};
     hipMemcpyFromSymbol(out, HIP_SYMBOL(inf_time), sizeof z);
     if (reset) hipMemcpyToSymbol(HIP_SYMBOL(inf_time), z, sizeof z);
 }
-#define INF_T(i) do { const unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(&inf_time[i], t_ - t_prev); t_prev = wall_clock64(); } while (0)
-#define INF_T0() unsigned long long t_prev = wall_clock64(); unsigned long long n_lit = 0, n_mat = 0, n_slow = 0
+#define INF_T(i) do { const unsigned long long t_ = wall_clock64(); t_acc[i] += t_ - t_prev; t_prev = t_; } while (0)
+#define INF_T0() unsigned long long t_prev = wall_clock64(); unsigned long long t_acc[16] = {}; unsigned long long n_lit = 0, n_mat = 0, n_slow = 0
 #define INF_N(x) x++
+#elif defined(ZGPU_INF_EXP_A)
+#define INF_T(i) do { if ((ZGPU_INF_EXP_A >> (i)) & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#define INF_T0() do { } while (0)
+#define INF_N(x) do { } while (0)
+#elif defined(ZGPU_INF_EXP_B)
+#define INF_T(i) do { if ((ZGPU_INF_EXP_B >> (i)) & 1) asm volatile("" ::: "memory"); } while (0)
+#define INF_T0() do { } while (0)
+#define INF_N(x) do { } while (0)
 #else
 #define INF_T(i) do { } while (0)
 #define INF_T0() do { } while (0)
@@ -126,13 +134,35 @@ __device__ inline uint32_t peek(const BitSrc &b, uint32_t n) { return (uint32_t)
 __device__ inline void drop(BitSrc &b, uint32_t n) { b.hold >>= n; b.bits -= n; }
 __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b.bits; }
 
+// v = the lane's bit of a wave mask ? a : b
+__device__ inline uint32_t sel_mask(uint64_t m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+// inclusive prefix sum over the 64 lanes (DPP: shifts inside the rows of 16, then the row totals passed on)
+template <int CTRL, int ROWS> __device__ inline uint32_t dpp_or_zero(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); }
+__device__ inline uint32_t wave_prefix_sum(uint32_t v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v); // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v); // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v); // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v); // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Build one decoding table from code lengths lens[0..n).  kind: 0 code-length code, 1 literal/length, 2 distance.
 // Acceptance rules of inflate_table (inftrees.c:106-138).  Returns 0 ok, 1 rejected.  Lane 0 does the serial part
 // (its small work arrays live in LDS: dynamically indexed private arrays would go to scratch memory).
-__constant__ const uint16_t kLBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ const uint8_t kLExt[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ const uint16_t kDBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ const uint8_t kDExt[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base value and extra bits of length symbol 257 + k and of distance symbol s (inflate_table's lbase/lext/dbase/dext,
+// inftrees.c:46-60, in closed form: no table in memory to wait for)
+__device__ inline uint32_t len_extra(uint32_t k) { return (k < 8 || k == 28) ? 0u : (k >> 2) - 1; }
+__device__ inline uint32_t len_base(uint32_t k) { return k < 8 ? 3 + k : k == 28 ? 258u : 3 + ((4 + (k & 3)) << ((k >> 2) - 1)); }
+__device__ inline uint32_t dist_extra(uint32_t s) { return s < 4 ? 0u : (s >> 1) - 1; }
+__device__ inline uint32_t dist_base(uint32_t s) { return s < 4 ? 1 + s : 1 + ((2 + (s & 1)) << ((s >> 1) - 1)); }
 __constant__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // table entry of symbol s with code length l.  kind: 0 code-length code (plain sym << 8 | len), 1 literal/length, 2 distance
@@ -143,10 +173,10 @@ __device__ inline uint32_t make_entry(uint32_t kind, uint32_t s, uint32_t l)
         if (s < 256) return l | kEntLit | (s << 16);
         if (s == 256) return l | kEntEob;
         if (s > 285) return l | kEntBad;
-        return l | ((uint32_t)kLExt[s - 257] << 4) | kEntLen | ((uint32_t)kLBase[s - 257] << 16);
+        return l | (len_extra(s - 257) << 4) | kEntLen | (len_base(s - 257) << 16);
     }
     if (s > 29) return l | kEntBad;
-    return l | ((uint32_t)kDExt[s] << 4) | kEntLen | ((uint32_t)kDBase[s] << 16);
+    return l | (dist_extra(s) << 4) | kEntLen | (dist_base(s) << 16);
 }
 
 __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
@@ -188,31 +218,37 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
     return rc;
 }
 
-// decode one symbol; returns the symbol, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code)
-// canonical walk (first-code method) over the low bits of `hold`: symbol | code length << 16 of a code of any length,
-// 0xFFFF if the pattern is not assigned.  Takes the bits by value: a reader passed by reference to a real call lives in
-// scratch memory, and every access of the decode loop to its own state then costs a trip to HBM.
-__device__ __noinline__ uint32_t decode_long(uint64_t h, const uint16_t *sorted, const uint16_t *count)
+// A code longer than the table, canonical first-code method with one code length per lane: lane l (1..15) holds, for its
+// table, the first code of length l, the number of codes of that length and where they start in the (length, symbol) order
+// (CodeRows, loaded after build_table); the pattern decodes at the one length whose code range holds its first l bits.
+// Returns symbol | length << 16, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code).
+struct CodeRows { uint32_t first, count, start; };
+__device__ inline CodeRows load_rows(const InflateLds &L, const uint16_t *count, uint32_t lane)
 {
-    int code = 0, first = 0, index = 0;
-    for (uint32_t l = 1; l <= 15; l++) {
-        code |= (int)(h & 1); h >>= 1;
-        const int c = count[l];
-        if (code - c < first) return (uint32_t)sorted[index + (code - first)] | (l << 16);
-        index += c; first += c; first <<= 1; code <<= 1;
-    }
-    return 0xFFFFu;
+    CodeRows r;
+    r.first = L.work_first[lane & 15]; r.start = L.work_start[lane & 15]; r.count = (lane >= 1 && lane < 16) ? count[lane] : 0u;
+    return r;
+}
+__device__ inline uint32_t long_code(uint32_t hbits, const CodeRows &r, const uint16_t *sorted, uint32_t lane)
+{
+    const uint32_t l = (lane & 15) ? (lane & 15) : 1, d = (__brev(hbits) >> (32 - l)) - r.first;
+    const bool hit = d < r.count; // (count is zero in the lanes that hold no length)
+    uint32_t sym = 0;
+    if (hit) sym = sorted[r.start + d];
+    const uint64_t m = __ballot(hit);
+    if (!m) return 0xFFFFu;
+    const uint32_t at = (uint32_t)__builtin_ctzll(m);
+    return (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)at) | (at << 16);
 }
 
-// decode one symbol of the code-length code (plain entries sym << 8 | len); 0xFFFF when the bit pattern is not assigned
-__device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits, const uint16_t *sorted, const uint16_t *count)
+// decode one symbol of the code-length code (plain entries sym << 8 | len; its codes all fit the 7-bit table); 0xFFFF when
+// the bit pattern is not assigned
+__device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t tbits)
 {
     const uint32_t e = uni(tab[peek(b, tbits)]);
-    if (e) { drop(b, e & 255); return e >> 8; }
-    const uint32_t r = uni(decode_long(b.hold, sorted, count));
-    if (r == 0xFFFFu) return r;
-    drop(b, r >> 16);
-    return r & 0xFFFFu;
+    if (!e) return 0xFFFFu;
+    drop(b, e & 255);
+    return e >> 8;
 }
 
 __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
@@ -300,6 +336,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         INF_T(3);
     };
     bool last = false, seen_final = false;
+    CodeRows lrows{}, drows{}; // per-length rows of the two codes of the current block (lanes 1..15)
     INF_T(0);
     while (!err && !last) {
         INF_T(2);
@@ -344,10 +381,12 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
             __syncthreads();
             build_table(L, L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
+            lrows = load_rows(L, L.lcount, lane);
             __syncthreads();
             for (uint32_t s = lane; s < 32; s += 64) L.lens[s] = 5;
             __syncthreads();
             build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
+            drows = load_rows(L, L.dcount, lane);
         } else {
             refill(b, L.stage);
             const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
@@ -368,7 +407,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             while (have < nlen + ndist) {
                 stage_fill(b, L.stage, lane);
                 refill(b, L.stage);
-                const uint32_t s = decode_sym(b, L.dtab, 7, L.dsym, L.dcount);
+                const uint32_t s = decode_sym(b, L.dtab, 7);
                 if (s == 0xFFFFu) { err = kMsgCodeLens; break; }
                 if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
                 uint32_t rep, val = 0;
@@ -389,8 +428,10 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             if (lane == 0 && c == 0) { printf("nlen %u ndist %u ncode %u have %u\n", nlen, ndist, ncode, have); for (uint32_t i = 0; i < nlen + ndist; i++) printf("%u ", (unsigned)L.lens[i]); printf("\n"); }
 #endif
             if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
+            lrows = load_rows(L, L.lcount, lane);
             __syncthreads();
             if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
+            drows = load_rows(L, L.dcount, lane);
         }
         __syncthreads();
         INF_T(1);
@@ -407,43 +448,53 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             b.rd = pos >> 5; b.filled = uni(b.filled);
             stage_fill(b, L.stage, lane);
             if (pos > b.seg_bits) { err = kMsgTruncated; break; }
-            uint32_t info; // bits 0-5 token length in bits, 6-7 kind (0 stop, 1 literal, 2 match), 8-16 bytes produced, 17-31 distance - 1
-            uint32_t lit_byte;
+            uint32_t info; // bits 0-6 token length in bits (64 ends the walk), 7-8 kind (0 stop, 1 literal, 2 match), 9-17 bytes produced
+            uint32_t lit_byte, dist;
             {
                 const uint32_t p = pos + lane, wi = p >> 5, sh = p & 31;
                 const uint32_t w0 = L.stage[wi & (kStageDwords - 1)], w1 = L.stage[(wi + 1) & (kStageDwords - 1)], w2 = L.stage[(wi + 2) & (kStageDwords - 1)];
                 const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
                 const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
                 const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
-                const uint32_t len = (e >> 16) + ((lo >> l1) & ((1u << xl) - 1));
+                const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
                 const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
                 const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
                 const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
-                const uint32_t dist = (ed >> 16) + ((h2 >> l2) & ((1u << xd) - 1));
+                dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
                 lit_byte = e >> 16;
-                const uint32_t as_match = (t + l2 + xd) | (2u << 6) | (len << 8) | ((dist - 1) << 17);
-                const bool match_ok = (e & kEntLen) && (ed & kEntLen);
-                info = (e & kEntLit) ? (l1 | (1u << 6) | (1u << 8)) : match_ok ? as_match : 0u;
+                const uint32_t as_match = (t + l2 + xd) | (2u << 7) | (len << 9), as_lit = l1 | (1u << 7) | (1u << 9);
+                const uint32_t m = (e & ed & kEntLen) ? as_match : 64u;
+                info = (e & kEntLit) ? as_lit : m;
             }
-            uint32_t cur = 0, oc = o, offv = 0xFFFFFFFFu;
-            uint64_t mm = 0;
-            while (cur < 64) {
-                const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur);
-                const uint32_t kind = (inf >> 6) & 3u, ol = (inf >> 8) & 511u;
-                if (kind == 0 || oc + ol > chunk_size) break;
-                if (kind == 2) { if ((inf >> 17) >= oc + reach) break; mm |= 1ull << cur; }
-                offv = lane == cur ? oc : offv;
-                oc += ol; cur += inf & 63u;
-            }
-            if (oc != o || cur != 0) {
-                if (offv != 0xFFFFFFFFu && (info & (1u << 6))) L.out[offv & (kOutRing - 1)] = (uint8_t)lit_byte;
+            INF_T(8);
+            // the walk: token starts from offset 0 on (a stop token is marked too and ends it)
+            uint64_t marks = 0;
+            uint32_t cur = 0;
+            do { marks |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur) & 127u; } while (cur < 64);
+            // output positions: prefix sum of the bytes the marked tokens produce
+            const uint32_t kind = (info >> 7) & 3u, ol = sel_mask(marks, info >> 9, 0u);
+            const uint32_t incl = wave_prefix_sum(ol), offv = o + incl - ol;
+            const bool ok = kind != 0 && offv + ol <= chunk_size && (kind != 2 || dist - 1 < offv + reach);
+            const uint64_t bad = __ballot(!ok) & marks;
+            uint32_t oc;
+            if (bad) { // the first token the round cannot take ends it: the one-symbol path looks at that one
+                cur = (uint32_t)__builtin_ctzll(bad);
+                marks &= (1ull << cur) - 1;
+                oc = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)cur);
+            } else oc = o + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            INF_T(9);
+            if (cur != 0) {
+                if (sel_mask(marks, kind, 0u) == 1) L.out[offv & (kOutRing - 1)] = (uint8_t)lit_byte;
                 INF_N(n_lit); // (rounds)
+                INF_T(10);
+                uint64_t mm = marks & __ballot(kind == 2);
                 while (mm) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
                     const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
-                    copy_match(mo, (inf >> 8) & 511u, (inf >> 17) + 1);
+                    copy_match(mo, (inf >> 9) & 511u, (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)l));
                     INF_N(n_mat);
                 }
+                INF_T(11);
                 pos += cur; o = oc;
                 if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
                 continue;
@@ -456,7 +507,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
             uint32_t e = uni(L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)]);
             if (e) drop(b, e & 15u);
             else { // a code longer than the table, or no code at all
-                const uint32_t s2 = uni(decode_long(b.hold, L.lsym, L.lcount));
+                const uint32_t s2 = long_code((uint32_t)b.hold, lrows, L.lsym, lane);
                 if (s2 == 0xFFFFu) { err = kMsgLitCode; break; }
                 drop(b, s2 >> 16);
                 e = make_entry(1, s2 & 0xFFFFu, 0);
@@ -474,7 +525,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
                 uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
                 if (ed) drop(b, ed & 15u);
                 else {
-                    const uint32_t d2 = uni(decode_long(b.hold, L.dsym, L.dcount));
+                    const uint32_t d2 = long_code((uint32_t)b.hold, drows, L.dsym, lane);
                     if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
                     drop(b, d2 >> 16);
                     ed = make_entry(2, d2 & 0xFFFFu, 0);
@@ -488,6 +539,7 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
                 o += len;
             }
             pos = consumed_bits(b);
+            INF_T(12);
             if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
         }
         // the scalar reader takes over again at the block boundary (or holds the position an error was found at)
@@ -520,7 +572,8 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
 #ifdef ZGPU_INF_TIME
-        atomicAdd(&inf_time[5], n_lit); atomicAdd(&inf_time[6], n_mat); atomicAdd(&inf_time[7], n_slow);
+        t_acc[5] = n_lit; t_acc[6] = n_mat; t_acc[7] = n_slow;
+        for (int i_ = 0; i_ < 16; i_++) atomicAdd(&inf_time[i_], t_acc[i_]);
 #endif
         if (meta) { meta[c].out_bytes = err ? 0 : o; meta[c].ntok = 0; meta[c].adler_a = 1; meta[c].adler_b = 0; meta[c].in_bytes = 0; meta[c].data_type = 2; }
     }
