@@ -25,7 +25,7 @@ e.inflate_device(dst.data_ptr(), r.out_bytes, offs.data_ptr(), n, back.data_ptr(
 torch.cuda.synchronize()
 f(out, 0)
 assert torch.equal(src, back)
-names = {0: "0 setup", 1: "1 header+tables", 2: "2 symbols (rest)", 3: "3 flush", 4: "4 end", 8: "8 lane decode", 9: "9 walk", 10: "10 literals", 11: "11 matches", 12: "12 one-symbol"}
+names = {0: "0 setup", 1: "R header+tables", 3: "W flush", 4: "W end", 8: "R lane decode", 9: "R walk+emit", 10: "W scan+literals", 11: "W matches", 12: "R one-symbol", 13: "R waits", 14: "W waits"}
 tot = sum(int(out[i]) for i in names)
 for i, nm in names.items():
     print("%-16s %8.1f us/chunk  %5.1f%%" % (nm, int(out[i]) / n / 100.0, 100.0 * int(out[i]) / tot))  # wall_clock64: 100 MHz

@@ -44,7 +44,7 @@ static const char *const kInfMessages[kMsgCount] = {
 
 struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t pad; };
 
-constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 512;
+constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 256;
 constexpr uint32_t kOutRing = 32768, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
 
 // Decoding table entries of the literal/length and distance codes carry everything the symbol loop needs:
@@ -56,6 +56,8 @@ struct InflateLds {
     uint32_t ltab[1 << kLBits]; // 0 = code longer than kLBits (or unassigned)
     uint32_t dtab[1 << kDBits];
     uint32_t stage[kStageDwords]; // ring of input dwords
+    uint32_t tok[128];            // token ring, reader -> writer, handed over in halves of 64
+    uint32_t abort_flag, pad0;    // writer -> reader: stop, the output is void
     uint16_t lens[320];
     uint16_t lsym[288], dsym[32]; // symbols sorted by (length, symbol) for the long-code walk
     uint16_t lcount[16], dcount[16];
@@ -113,16 +115,16 @@ __device__ inline void settle(BitSrc &b) // (the compiler cannot see that loop-c
 
 __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
 {
-    // keep at least 256 dwords ahead of the reader; each call loads 256 dwords (16 bytes per lane)
-    while (b.filled - b.rd < 256) {
-        const uint64_t i = b.d0 + b.filled + lane * 4;
-        uint32_t v[4];
+    // keep at least 128 dwords ahead of the reader; each call loads 128 dwords (8 bytes per lane)
+    while (b.filled - b.rd < 128) {
+        const uint64_t i = b.d0 + b.filled + lane * 2;
+        uint32_t v[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i + k < b.gdwords) ? b.g32[i + k] : 0u;
-        const uint32_t s = (b.filled + lane * 4) & (kStageDwords - 1);
+        for (int k = 0; k < 2; k++) v[k] = (i + k < b.gdwords) ? b.g32[i + k] : 0u;
+        const uint32_t s = (b.filled + lane * 2) & (kStageDwords - 1);
 #pragma unroll
-        for (int k = 0; k < 4; k++) stage[s + k] = v[k];
-        b.filled += 256;
+        for (int k = 0; k < 2; k++) stage[s + k] = v[k];
+        b.filled += 128;
     }
 }
 __device__ inline void refill(BitSrc &b, const uint32_t *stage)
@@ -133,6 +135,9 @@ __device__ inline void prime(BitSrc &b, const uint32_t *stage) { b.nx = stage[b.
 __device__ inline uint32_t peek(const BitSrc &b, uint32_t n) { return (uint32_t)b.hold & ((1u << n) - 1); }
 __device__ inline void drop(BitSrc &b, uint32_t n) { b.hold >>= n; b.bits -= n; }
 __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b.bits; }
+
+// one wave's LDS operations complete in order: ordering its own writes and reads needs the compiler held back, no barrier
+__device__ inline void wave_sync() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // v = the lane's bit of a wave mask ? a : b
 __device__ inline uint32_t sel_mask(uint64_t m, uint32_t a, uint32_t b)
@@ -182,7 +187,7 @@ __device__ inline uint32_t make_entry(uint32_t kind, uint32_t s, uint32_t l)
 __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
                                              uint16_t *sorted, uint16_t *count, uint32_t lane)
 {
-    __syncthreads();
+    wave_sync();
     for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
     if (lane == 0) {
         uint16_t *cnt = count, *offs = L.work_offs, *first = L.work_first, *start = L.work_start;
@@ -202,7 +207,7 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
         if (!rc) for (uint32_t s2 = 0; s2 < n; s2++) { const uint32_t l = lens[s2]; if (l) sorted[offs[l]++] = (uint16_t)s2; }
         L.build_rc = rc;
     }
-    __syncthreads();
+    wave_sync();
     const uint32_t rc = L.build_rc;
     if (rc == 0) {
         // symbol number j in (length, symbol) order has the canonical code first[l] + (j - start[l])
@@ -214,7 +219,7 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     return rc;
 }
 
@@ -251,14 +256,28 @@ __device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t t
     return e >> 8;
 }
 
-__global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
-                                                     uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
-                                                     uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
-                                                     const uint8_t *__restrict__ dict, uint32_t dict_len)
+// One workgroup of two waves per segment.  Wave 0 (the reader) owns the bit stream: block headers, code tables and the
+// token decode; it never needs to know how many bytes came out so far.  Wave 1 (the writer) owns the output: the 32 KiB
+// ring in LDS, match copies, flushes to the destination, and the limits that depend on the output position (distance too
+// far back, chunk size).  Tokens travel through a ring of 128 words in LDS, handed over in halves of 64 with one workgroup
+// barrier per half: while the writer executes half k the reader fills half k + 1.
+// token word: bits 0-1 kind (0 nothing, 1 literal, 2 match, 3 command)
+//   literal: bits 2-9 byte;  match: bits 2-10 length, 11-25 distance - 1
+//   command: bits 2-3 which (1 stored bytes: bits 4-20 count, the next two words = offset of the bytes in the input;
+//            2 end of the segment: bits 4-11 the reader's verdict)
+enum : uint32_t { kCmdStored = 1, kCmdEnd = 2 };
+
+__device__ inline void block_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+__global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
+                                                      uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
+                                                      uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
+                                                      const uint8_t *__restrict__ dict, uint32_t dict_len)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t role = uni(threadIdx.x >> 6); // 0 reader, 1 writer
     if (c >= nchunks) return;
     const uint64_t gc = chunk0 + c, seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
     const bool must_be_final = gc == last_chunk;
@@ -266,35 +285,270 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
     // concatenated afterwards (used for streams whose chunks are not all full, e.g. flushed mid-chunk)
     const bool compact = chunk_size_arg == 0;
     const uint32_t chunk_size = compact ? kChunkMax : chunk_size_arg;
-    uint32_t err = kMsgNone;
-    INF_T0();
-
-    BitSrc b;
-    const uint64_t in_addr = reinterpret_cast<uint64_t>(in);
-    const uint64_t abs_lo = in_addr + seg_lo, abs_al = abs_lo & ~3ull;
-    b.g32 = reinterpret_cast<const uint32_t *>(abs_al);
-    b.gdwords = (in_addr + in_bytes - abs_al + 3) >> 2; // reads past the input buffer are replaced by zeros, see stage_fill
-    // the dword holding the last input bytes may extend past the buffer by up to 3 bytes inside the same aligned dword
-    b.d0 = 0; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
-    const uint32_t lead = (uint32_t)(abs_lo - abs_al);
-    b.seg_bits = (uint32_t)(seg_hi - seg_lo + lead) * 8;
-    stage_fill(b, L.stage, lane);
-    __syncthreads();
-    prime(b, L.stage);
-    refill(b, L.stage); refill(b, L.stage);
-    drop(b, lead * 8);
-
-    uint32_t o = 0;       // bytes produced
     // a preset dictionary (inflateSetDictionary, inflate.c:1200-1236) is what the window holds before the first byte: in the ring it
     // sits right below position 0, and the first segment may reach that much farther back
     const uint32_t reach = (gc == 0) ? dict_len : 0u;
+    if (threadIdx.x == 0) L.abort_flag = 0;
+    INF_T0();
+
+    if (role == 0) {
+        // =========================================== reader ===========================================
+        uint32_t err = kMsgNone;
+        uint32_t wr = 0;   // tokens put into the ring so far
+        bool stop = false; // the writer gave up (its error comes first in stream order)
+        auto publish = [&]() { // the current half is complete: hand it over, the other half is free from here on
+            INF_T(9);
+            block_sync();
+            INF_T(13);
+            stop = uni(L.abort_flag) != 0;
+        };
+        // the marked lanes' token words, in lane order
+        auto emit_tokens = [&](uint64_t marks, uint32_t word) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(marks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)marks, 0u));
+            const uint32_t t = (uint32_t)__builtin_popcountll(marks), bound = (wr | 63u) + 1, at = wr + rank;
+            const bool mine = sel_mask(marks, 1u, 0u) != 0;
+            if (mine && at < bound) L.tok[at & 127u] = word;
+            if (wr + t >= bound) {
+                publish();
+                if (mine && at >= bound) L.tok[at & 127u] = word;
+            }
+            wr += t;
+        };
+        // n <= 3 words that must sit in one half (lane i holds word i); `final`: pad the half and hand it over
+        auto emit_command = [&](uint32_t word, uint32_t n, bool final) {
+            if ((wr & 63u) + n > 64u) { // no room: pad this half with nothing-tokens
+                const uint32_t bound = (wr | 63u) + 1;
+                if (wr + lane < bound) L.tok[(wr + lane) & 127u] = 0u;
+                wr = bound;
+                publish();
+            }
+            if (lane < n) L.tok[(wr + lane) & 127u] = word;
+            wr += n;
+            if (final) {
+                const uint32_t bound = ((wr - 1) | 63u) + 1;
+                if (wr + lane < bound) L.tok[(wr + lane) & 127u] = 0u;
+                wr = bound;
+                publish();
+            } else if ((wr & 63u) == 0) publish();
+        };
+        BitSrc b;
+        const uint64_t in_addr = reinterpret_cast<uint64_t>(in);
+        const uint64_t abs_lo = in_addr + seg_lo, abs_al = abs_lo & ~3ull;
+        b.g32 = reinterpret_cast<const uint32_t *>(abs_al);
+        b.gdwords = (in_addr + in_bytes - abs_al + 3) >> 2; // reads past the input buffer are replaced by zeros, see stage_fill
+        // the dword holding the last input bytes may extend past the buffer by up to 3 bytes inside the same aligned dword
+        b.d0 = 0; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+        const uint32_t lead = (uint32_t)(abs_lo - abs_al);
+        b.seg_bits = (uint32_t)(seg_hi - seg_lo + lead) * 8;
+        stage_fill(b, L.stage, lane);
+        wave_sync();
+        prime(b, L.stage);
+        refill(b, L.stage); refill(b, L.stage);
+        drop(b, lead * 8);
+        auto reposition = [&](uint32_t pos) { // the scalar reader at bit `pos` of the staged dwords
+            b.rd = pos >> 5; b.hold = 0; b.bits = 0;
+            prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
+            drop(b, pos & 31);
+        };
+        bool last = false, seen_final = false;
+        CodeRows lrows{}, drows{}; // per-length rows of the two codes of the current block (lanes 1..15)
+        INF_T(0);
+        while (!err && !last && !stop) {
+            if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
+            stage_fill(b, L.stage, lane); wave_sync();
+            refill(b, L.stage);
+            const uint32_t hdr = peek(b, 3); drop(b, 3);
+            last = hdr & 1; seen_final = seen_final || last;
+            const uint32_t type = hdr >> 1;
+            if (type == 3) { err = kMsgBlockType; break; }
+            if (type == 0) {
+                drop(b, b.bits & 7);
+                refill(b, L.stage);
+                const uint32_t len = peek(b, 16); drop(b, 16);
+                refill(b, L.stage);
+                const uint32_t nlen = peek(b, 16); drop(b, 16);
+                if (len != (nlen ^ 0xFFFFu)) { err = kMsgStoredLen; break; }
+                const uint32_t bytepos = consumed_bits(b) >> 3; // from the reader's current origin (dword b.d0 of the segment)
+                if ((uint64_t)bytepos + len > (b.seg_bits >> 3)) { err = kMsgTruncated; break; }
+                const uint64_t src = reinterpret_cast<uint64_t>(b.g32 + b.d0) + bytepos - in_addr; // the writer copies the bytes from the input
+                emit_command(lane == 0 ? (3u | (kCmdStored << 2) | (len << 4)) : lane == 1 ? (uint32_t)src : (uint32_t)(src >> 32), 3, false);
+                // reposition the reader right after the stored bytes: new origin = the dword holding that byte
+                const uint32_t np = bytepos + len;
+                b.d0 += np >> 2; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+                b.seg_bits -= (np & ~3u) * 8; // seg_bits stays relative to the origin
+                wave_sync();
+                stage_fill(b, L.stage, lane); wave_sync();
+                prime(b, L.stage);
+                refill(b, L.stage); refill(b, L.stage);
+                drop(b, (np & 3) * 8);
+                continue;
+            }
+            // ---- tables ----
+            if (type == 1) {
+                for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                wave_sync();
+                build_table(L, L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
+                lrows = load_rows(L, L.lcount, lane);
+                wave_sync();
+                for (uint32_t s = lane; s < 32; s += 64) L.lens[s] = 5;
+                wave_sync();
+                build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
+                drows = load_rows(L, L.dcount, lane);
+            } else {
+                refill(b, L.stage);
+                const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
+                const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
+                const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
+                if (nlen > 286 || ndist > 30) { err = kMsgTooMany; break; }
+                wave_sync();
+                for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+                wave_sync();
+                for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
+                wave_sync();
+                // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
+                if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
+                wave_sync();
+                for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+                wave_sync();
+                uint32_t have = 0, prev = 0;
+                while (have < nlen + ndist) {
+                    stage_fill(b, L.stage, lane);
+                    refill(b, L.stage);
+                    const uint32_t s = decode_sym(b, L.dtab, 7);
+                    if (s == 0xFFFFu) { err = kMsgCodeLens; break; }
+                    if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
+                    uint32_t rep, val = 0;
+                    refill(b, L.stage);
+                    if (s == 16) { if (have == 0) { err = kMsgRepeat; break; } val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
+                    else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
+                    else { rep = 11 + peek(b, 7); drop(b, 7); }
+                    if (have + rep > nlen + ndist) { err = kMsgRepeat; break; }
+                    if (lane < rep) L.lens[have + lane] = (uint16_t)val;
+                    if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
+                    if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
+                    prev = val; have += rep;
+                }
+                if (err) break;
+                wave_sync();
+                if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
+                lrows = load_rows(L, L.lcount, lane);
+                wave_sync();
+                if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
+                drows = load_rows(L, L.dcount, lane);
+            }
+            wave_sync();
+            INF_T(1);
+            // ---- symbols ----
+            // Every lane decodes the token that would start at its own bit offset behind the reader (both table lookups, extra
+            // bits included); a scalar walk from offset 0 then picks the lanes that really are token starts (each token says
+            // where the next one begins).  A token the tables do not resolve (code longer than the table, end of block, invalid
+            // code, the end of the segment) ends the walk and goes through the one-symbol path below.
+            uint32_t pos = consumed_bits(b); // the reader's position in bits from the segment's origin dword
+            bool eob = false;
+            while (!eob && !stop) {
+                pos = uni(pos);
+                b.rd = pos >> 5; b.filled = uni(b.filled); b.seg_bits = uni(b.seg_bits);
+                stage_fill(b, L.stage, lane);
+                if (pos > b.seg_bits) { err = kMsgTruncated; break; }
+                uint32_t info, word; // info: bits 0-6 token length in bits (64 = not a token the walk may take)
+                {
+                    const uint32_t p = pos + lane, wi = p >> 5, sh = p & 31;
+                    const uint32_t w0 = L.stage[wi & (kStageDwords - 1)], w1 = L.stage[(wi + 1) & (kStageDwords - 1)], w2 = L.stage[(wi + 2) & (kStageDwords - 1)];
+                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                    const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
+                    const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
+                    const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
+                    const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
+                    const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
+                    const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
+                    const uint32_t dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
+                    const bool is_lit = e & kEntLit, is_match = e & ed & kEntLen;
+                    const uint32_t nb = is_lit ? l1 : t + l2 + xd;
+                    info = ((is_lit || is_match) && p + nb <= b.seg_bits) ? nb : 64u;
+                    word = is_lit ? (1u | ((e >> 16) << 2)) : (2u | (len << 2) | ((dist - 1) << 11));
+                }
+                INF_T(8);
+                // the walk: token starts from offset 0 on (a lane that is not a token is marked too and ends it)
+                uint64_t marks = 0;
+                uint32_t cur = 0;
+                do { marks |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur); } while (cur < 64);
+                const uint64_t bad = __ballot(info == 64u) & marks;
+                if (bad) { cur = (uint32_t)__builtin_ctzll(bad); marks &= (1ull << cur) - 1; }
+                if (cur != 0) {
+                    emit_tokens(marks, word);
+                    INF_N(n_lit); // (rounds)
+                    INF_T(9);
+                    pos += cur;
+                    continue;
+                }
+                // ---- one symbol through the scalar reader ----
+                INF_N(n_slow);
+                reposition(pos);
+                uint32_t e = uni(L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)]);
+                if (e) drop(b, e & 15u);
+                else { // a code longer than the table, or no code at all
+                    const uint32_t s2 = long_code((uint32_t)b.hold, lrows, L.lsym, lane);
+                    if (s2 == 0xFFFFu) { err = kMsgLitCode; break; }
+                    drop(b, s2 >> 16);
+                    e = make_entry(1, s2 & 0xFFFFu, 0);
+                }
+                uint32_t tokw;
+                if (e & kEntLit) tokw = 1u | ((e >> 16) << 2);
+                else {
+                    if (e & kEntEob) { eob = true; pos = consumed_bits(b); if (pos > b.seg_bits) err = kMsgTruncated; break; }
+                    if (e & kEntBad) { err = kMsgLitCode; break; }
+                    const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
+                    drop(b, xl);
+                    refill(b, L.stage);
+                    uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
+                    if (ed) drop(b, ed & 15u);
+                    else {
+                        const uint32_t d2 = long_code((uint32_t)b.hold, drows, L.dsym, lane);
+                        if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
+                        drop(b, d2 >> 16);
+                        ed = make_entry(2, d2 & 0xFFFFu, 0);
+                    }
+                    if (ed & kEntBad) { err = kMsgDistCode; break; }
+                    const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
+                    drop(b, xd);
+                    tokw = 2u | (len << 2) | ((dist - 1) << 11);
+                }
+                pos = consumed_bits(b);
+                if (pos > b.seg_bits) { err = kMsgTruncated; break; } // the token runs past the end of the segment
+                emit_tokens(1ull, tokw);
+                INF_T(12);
+            }
+            // the scalar reader takes over again at the block boundary
+            if (eob && !err) reposition(pos);
+            else if (err == kMsgTruncated && !eob) reposition(pos);
+        }
+        // an error found in bits that lie past the end of the segment is the zero padding talking: the segment is truncated
+        if (err && consumed_bits(b) > b.seg_bits) err = kMsgTruncated;
+        if (!err && !stop) {
+            const uint32_t used = consumed_bits(b);
+            if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
+            else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
+            else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
+            else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
+        }
+#ifdef ZGPU_INF_DEBUG2
+        if (err && lane == 0) printf("chunk %u reader err %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
+#endif
+        emit_command(3u | (kCmdEnd << 2) | (err << 4), 1, true);
+#ifdef ZGPU_INF_TIME
+        if (lane == 0) { t_acc[5] = n_lit; t_acc[7] = n_slow; for (int i_ = 0; i_ < 16; i_++) if (t_acc[i_]) atomicAdd(&inf_time[i_], t_acc[i_]); }
+#endif
+        return;
+    }
+
+    // =========================================== writer ===========================================
+    uint32_t err = kMsgNone;
+    uint32_t o = 0;       // bytes produced
     for (uint32_t i = lane; i < reach; i += 64) L.out[(kOutRing - reach + i) & (kOutRing - 1)] = dict[i];
-    __syncthreads();
     uint32_t flushed = 0; // bytes already copied from the LDS ring to the destination (a multiple of kOutHalf until the end)
     bool nofit = false;   // direct placement: the destination ended before the chunk did
     uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
     const uint64_t dst_room = compact ? kChunkMax : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
-    // copy bytes [flushed, upto) of the output to the destination; the range never wraps in the ring
     // copy a match of `len` bytes at distance `dist` to output position `at`; a distance shorter than the length repeats its
     // pattern (byte-sequential semantics of inffast.c:246-259).  The ring holds the last 32 KiB: a read at the full distance
     // 32768 hits the slot its own lane is about to write.
@@ -319,8 +573,10 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         }
         __builtin_amdgcn_wave_barrier();
     };
+    // copy bytes [flushed, upto) of the output to the destination; the range never wraps in the ring
     auto flush_to = [&](uint32_t upto) {
-        INF_T(2);
+        INF_T(11);
+        wave_sync();
         uint32_t nbytes = upto - flushed;
         if ((uint64_t)flushed + nbytes > dst_room) { nofit = true; nbytes = dst_room > flushed ? (uint32_t)(dst_room - flushed) : 0; }
         const uint8_t *src_r = L.out + (flushed & (kOutRing - 1));
@@ -335,235 +591,83 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         flushed = upto;
         INF_T(3);
     };
-    bool last = false, seen_final = false;
-    CodeRows lrows{}, drows{}; // per-length rows of the two codes of the current block (lanes 1..15)
+    uint32_t reader_err = kMsgNone;
     INF_T(0);
-    while (!err && !last) {
-        INF_T(2);
-        if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
-        stage_fill(b, L.stage, lane); __syncthreads();
-        refill(b, L.stage);
-        const uint32_t hdr = peek(b, 3); drop(b, 3);
-        last = hdr & 1; seen_final = seen_final || last;
-        const uint32_t type = hdr >> 1;
-        if (type == 3) { err = kMsgBlockType; break; }
-        if (type == 0) {
-            drop(b, b.bits & 7);
-            refill(b, L.stage);
-            const uint32_t len = peek(b, 16); drop(b, 16);
-            refill(b, L.stage);
-            const uint32_t nlen = peek(b, 16); drop(b, 16);
-            if (len != (nlen ^ 0xFFFFu)) { err = kMsgStoredLen; break; }
-            const uint32_t bytepos = consumed_bits(b) >> 3; // from the reader's current origin (dword b.d0 of the segment)
-            if ((uint64_t)bytepos + len > (b.seg_bits >> 3)) { err = kMsgTruncated; break; }
-            if (o + len > chunk_size) { err = kMsgOutput; break; }
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(b.g32 + b.d0) + bytepos;
-            for (uint32_t done = 0; done < len;) { // through the ring, half by half
-                const uint32_t room = flushed + kOutHalf - o, part = len - done < room ? len - done : room;
-                for (uint32_t i = lane; i < part; i += 64) L.out[(o + i) & (kOutRing - 1)] = src[done + i];
-                o += part; done += part;
-                __syncthreads();
-                if (o == flushed + kOutHalf) flush_to(o);
-            }
-            // reposition the reader right after the stored bytes: new origin = the dword holding that byte
-            const uint32_t np = bytepos + len;
-            b.d0 += np >> 2; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
-            b.seg_bits -= (np & ~3u) * 8; // seg_bits stays relative to the origin
-            __syncthreads();
-            stage_fill(b, L.stage, lane); __syncthreads();
-            prime(b, L.stage);
-            refill(b, L.stage); refill(b, L.stage);
-            drop(b, (np & 3) * 8);
-            continue;
-        }
-        // ---- tables ----
-        if (type == 1) {
-            for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = (uint16_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-            __syncthreads();
-            build_table(L, L.lens, 288, 1, kLBits, L.ltab, L.lsym, L.lcount, lane);
-            lrows = load_rows(L, L.lcount, lane);
-            __syncthreads();
-            for (uint32_t s = lane; s < 32; s += 64) L.lens[s] = 5;
-            __syncthreads();
-            build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
-            drows = load_rows(L, L.dcount, lane);
-        } else {
-            refill(b, L.stage);
-            const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
-            const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
-            const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
-            if (nlen > 286 || ndist > 30) { err = kMsgTooMany; break; }
-            __syncthreads();
-            for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-            __syncthreads();
-            for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
-            __syncthreads();
-            // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
-            if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
-            __syncthreads();
-            for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-            __syncthreads();
-            uint32_t have = 0, prev = 0;
-            while (have < nlen + ndist) {
-                stage_fill(b, L.stage, lane);
-                refill(b, L.stage);
-                const uint32_t s = decode_sym(b, L.dtab, 7);
-                if (s == 0xFFFFu) { err = kMsgCodeLens; break; }
-                if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
-                uint32_t rep, val = 0;
-                refill(b, L.stage);
-                if (s == 16) { if (have == 0) { err = kMsgRepeat; break; } val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
-                else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
-                else { rep = 11 + peek(b, 7); drop(b, 7); }
-                if (have + rep > nlen + ndist) { err = kMsgRepeat; break; }
-                if (lane < rep) L.lens[have + lane] = (uint16_t)val;
-                if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
-                if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
-                prev = val; have += rep;
-            }
-            if (err) break;
-            __syncthreads();
-            asm volatile("" ::: "memory");
-#ifdef ZGPU_INF_DEBUG
-            if (lane == 0 && c == 0) { printf("nlen %u ndist %u ncode %u have %u\n", nlen, ndist, ncode, have); for (uint32_t i = 0; i < nlen + ndist; i++) printf("%u ", (unsigned)L.lens[i]); printf("\n"); }
-#endif
-            if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
-            lrows = load_rows(L, L.lcount, lane);
-            __syncthreads();
-            if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
-            drows = load_rows(L, L.dcount, lane);
-        }
-        __syncthreads();
-        INF_T(1);
-        // ---- symbols ----
-        // Every lane decodes the token that would start at its own bit offset behind the reader (both table lookups, extra
-        // bits included); a scalar walk from offset 0 then picks the lanes that really are token starts (each token says
-        // where the next one begins) and hands out their output positions.  Literals are stored by their lanes at once,
-        // matches are copied one after the other.  A token the tables do not resolve (code longer than the table, end of
-        // block, invalid code, output limit, distance too far) ends the walk and goes through the one-symbol path below.
-        uint32_t pos = consumed_bits(b); // the reader's position in bits from the segment's origin dword
-        uint32_t how = 0;                // 1 end of block, 2 error
-        while (how == 0) {
-            pos = uni(pos); o = uni(o); flushed = uni(flushed);
-            b.rd = pos >> 5; b.filled = uni(b.filled);
-            stage_fill(b, L.stage, lane);
-            if (pos > b.seg_bits) { err = kMsgTruncated; break; }
-            uint32_t info; // bits 0-6 token length in bits (64 ends the walk), 7-8 kind (0 stop, 1 literal, 2 match), 9-17 bytes produced
-            uint32_t lit_byte, dist;
-            {
-                const uint32_t p = pos + lane, wi = p >> 5, sh = p & 31;
-                const uint32_t w0 = L.stage[wi & (kStageDwords - 1)], w1 = L.stage[(wi + 1) & (kStageDwords - 1)], w2 = L.stage[(wi + 2) & (kStageDwords - 1)];
-                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-                const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
-                const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
-                const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
-                const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
-                const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
-                const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
-                dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
-                lit_byte = e >> 16;
-                const uint32_t as_match = (t + l2 + xd) | (2u << 7) | (len << 9), as_lit = l1 | (1u << 7) | (1u << 9);
-                const uint32_t m = (e & ed & kEntLen) ? as_match : 64u;
-                info = (e & kEntLit) ? as_lit : m;
-            }
-            INF_T(8);
-            // the walk: token starts from offset 0 on (a stop token is marked too and ends it)
-            uint64_t marks = 0;
-            uint32_t cur = 0;
-            do { marks |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur) & 127u; } while (cur < 64);
-            // output positions: prefix sum of the bytes the marked tokens produce
-            const uint32_t kind = (info >> 7) & 3u, ol = sel_mask(marks, info >> 9, 0u);
-            const uint32_t incl = wave_prefix_sum(ol), offv = o + incl - ol;
-            const bool ok = kind != 0 && offv + ol <= chunk_size && (kind != 2 || dist - 1 < offv + reach);
-            const uint64_t bad = __ballot(!ok) & marks;
-            uint32_t oc;
-            if (bad) { // the first token the round cannot take ends it: the one-symbol path looks at that one
-                cur = (uint32_t)__builtin_ctzll(bad);
-                marks &= (1ull << cur) - 1;
-                oc = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)cur);
-            } else oc = o + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            INF_T(9);
-            if (cur != 0) {
-                if (sel_mask(marks, kind, 0u) == 1) L.out[offv & (kOutRing - 1)] = (uint8_t)lit_byte;
-                INF_N(n_lit); // (rounds)
-                INF_T(10);
-                uint64_t mm = marks & __ballot(kind == 2);
-                while (mm) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
-                    const uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
-                    copy_match(mo, (inf >> 9) & 511u, (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)l));
-                    INF_N(n_mat);
+    for (uint32_t half = 0;; half++) {
+        block_sync(); // the reader has completed this half of the ring
+        INF_T(14);
+        const uint32_t tw = L.tok[(half & 1) * 64 + lane];
+        const uint32_t kind = tw & 3u;
+        uint64_t cmds = __ballot(kind == 3);
+        uint32_t from = 0; // lanes below are done
+        bool ended = false;
+        for (;;) { // runs of tokens between the commands of this half; after an error only the commands are followed
+            const uint32_t upto = cmds ? (uint32_t)__builtin_ctzll(cmds) : 64u;
+            if (!err) { // ---- the tokens in lanes [from, upto) ----
+                o = uni(o); flushed = uni(flushed);
+                const bool inr = lane >= from && lane < upto;
+                const uint32_t k2 = inr ? kind : 0u, len = (tw >> 2) & 511u, ol = k2 == 1 ? 1u : k2 == 2 ? len : 0u;
+                const uint32_t incl = wave_prefix_sum(ol), offv = o + incl - ol, o_end = o + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                // limits that depend on the output position, in the order inffast.c checks them for one token
+                const bool far = k2 == 2 && (tw >> 11) >= offv + reach, over = offv + ol > chunk_size;
+                const uint64_t bad = __ballot(far || over);
+                if (bad) err = ((__ballot(far) >> (uint32_t)__builtin_ctzll(bad)) & 1) ? kMsgTooFar : kMsgOutput;
+                uint64_t todo = bad ? 0ull : __ballot(ol != 0);
+                // Literals are stored by their lanes ahead of the match copies of the same pass.  The ring is exactly as long as
+                // the farthest distance, so a store that far ahead may hit what an earlier match still has to read: position
+                // q lands on the slot of q - 32768.  A pass therefore ends with the first match whose source would be reached
+                // by the pass's last byte (and with the half of the ring that is flushed next).
+                while (todo) {
+                    const uint32_t lim = flushed + kOutHalf;
+                    uint64_t take = todo & __ballot(offv < lim), rest = todo & ~take;
+                    uint32_t pend = rest ? (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)__builtin_ctzll(rest)) : o_end;
+                    const uint64_t hz = take & __ballot(k2 == 2 && offv + (kOutRing - 1) - (tw >> 11) < pend);
+                    if (hz) {
+                        take &= (2ull << (uint32_t)__builtin_ctzll(hz)) - 1; rest = todo & ~take;
+                        pend = rest ? (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)__builtin_ctzll(rest)) : o_end;
+                    }
+                    if (sel_mask(take, k2, 0u) == 1) L.out[offv & (kOutRing - 1)] = (uint8_t)(tw >> 2);
+                    INF_T(10);
+                    uint64_t mm = take & __ballot(k2 == 2);
+                    while (mm) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
+                        const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)tw, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
+                        copy_match(mo, (t2 >> 2) & 511u, (t2 >> 11) + 1);
+                        INF_N(n_mat);
+                    }
+                    todo = rest; o = pend;
+                    if (o >= lim) flush_to(lim);
+                    INF_T(11);
                 }
-                INF_T(11);
-                pos += cur; o = oc;
-                if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
-                continue;
             }
-            // ---- one symbol through the scalar reader ----
-            INF_N(n_slow);
-            b.rd = pos >> 5; b.hold = 0; b.bits = 0;
-            prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
-            drop(b, pos & 31);
-            uint32_t e = uni(L.ltab[(uint32_t)b.hold & ((1u << kLBits) - 1)]);
-            if (e) drop(b, e & 15u);
-            else { // a code longer than the table, or no code at all
-                const uint32_t s2 = long_code((uint32_t)b.hold, lrows, L.lsym, lane);
-                if (s2 == 0xFFFFu) { err = kMsgLitCode; break; }
-                drop(b, s2 >> 16);
-                e = make_entry(1, s2 & 0xFFFFu, 0);
-            }
-            if (e & kEntLit) {
-                if (o >= chunk_size) { err = kMsgOutput; break; }
-                L.out[o & (kOutRing - 1)] = (uint8_t)(e >> 16); // (every lane stores the same byte)
-                o++;
-            } else {
-                if (e & kEntEob) { how = 1; pos = consumed_bits(b); break; }
-                if (e & kEntBad) { err = kMsgLitCode; break; }
-                const uint32_t xl = (e >> 4) & 15u, len = (e >> 16) + peek(b, xl);
-                drop(b, xl);
-                refill(b, L.stage);
-                uint32_t ed = uni(L.dtab[(uint32_t)b.hold & ((1u << kDBits) - 1)]);
-                if (ed) drop(b, ed & 15u);
-                else {
-                    const uint32_t d2 = long_code((uint32_t)b.hold, drows, L.dsym, lane);
-                    if (d2 == 0xFFFFu) { err = kMsgDistCode; break; }
-                    drop(b, d2 >> 16);
-                    ed = make_entry(2, d2 & 0xFFFFu, 0);
+            if (upto == 64) break;
+            // ---- the command in lane upto ----
+            const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)tw, (int)upto);
+            if (((cw >> 2) & 3u) == kCmdEnd) { reader_err = (cw >> 4) & 255u; ended = true; break; }
+            if (!err) {
+                const uint64_t soff = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)tw, (int)((upto + 2) & 63u)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)tw, (int)((upto + 1) & 63u));
+                const uint8_t *src = in + soff;
+                const uint32_t slen = (cw >> 4) & 0x1FFFFu;
+                if (o + slen > chunk_size) err = kMsgOutput;
+                else for (uint32_t done = 0; done < slen;) { // through the ring, half by half
+                    const uint32_t room = flushed + kOutHalf - o, part = slen - done < room ? slen - done : room;
+                    for (uint32_t i = lane; i < part; i += 64) L.out[(o + i) & (kOutRing - 1)] = src[done + i];
+                    o += part; done += part;
+                    if (o == flushed + kOutHalf) flush_to(o);
                 }
-                if (ed & kEntBad) { err = kMsgDistCode; break; }
-                const uint32_t xd = (ed >> 4) & 15u, dist = (ed >> 16) + peek(b, xd);
-                drop(b, xd);
-                if (dist > o + reach) { err = kMsgTooFar; break; }
-                if (o + len > chunk_size) { err = kMsgOutput; break; }
-                copy_match(o, len, dist);
-                o += len;
             }
-            pos = consumed_bits(b);
-            INF_T(12);
-            if (o >= flushed + kOutHalf) flush_to(flushed + kOutHalf);
+            from = upto + 3;
+            cmds &= ~(7ull << upto);
         }
-        // the scalar reader takes over again at the block boundary (or holds the position an error was found at)
-        if (how == 1 || err == kMsgTruncated) {
-            b.rd = pos >> 5; b.hold = 0; b.bits = 0;
-            prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
-            drop(b, pos & 31);
-        }
+        if (ended) break;
+        if (err && lane == 0) L.abort_flag = 1; // void output: the reader stops at its next hand-over and sends its end command
     }
-    // an error found in bits that lie past the end of the segment is the zero padding talking: the segment is truncated
-    if (err && err != kMsgOutput && consumed_bits(b) > b.seg_bits) err = kMsgTruncated;
-    if (!err) {
-        const uint32_t used = consumed_bits(b);
-        if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
-        else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
-        else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
-        else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
-        else if (!compact && !must_be_final && o != chunk_size) err = kMsgShort; // direct placement assumes full chunks
-    }
+    if (!err) err = reader_err;
+    if (!err && !compact && !must_be_final && o != chunk_size) err = kMsgShort; // direct placement assumes full chunks
 #ifdef ZGPU_INF_DEBUG2
-    if (err && lane == 0) printf("chunk %u err %u o %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, o, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
+    if (err && lane == 0) printf("chunk %u err %u o %u\n", c, err, o);
 #endif
-    INF_T(2);
-    __syncthreads();
     // the rest of the chunk (an error leaves what was flushed before it was found; the status says the chunk is void)
     if (!err) flush_to(o);
     const bool fits = !nofit;
@@ -572,8 +676,8 @@ __global__ void __launch_bounds__(64) inflate_kernel(const uint8_t *__restrict__
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
 #ifdef ZGPU_INF_TIME
-        t_acc[5] = n_lit; t_acc[6] = n_mat; t_acc[7] = n_slow;
-        for (int i_ = 0; i_ < 16; i_++) atomicAdd(&inf_time[i_], t_acc[i_]);
+        t_acc[6] = n_mat;
+        for (int i_ = 0; i_ < 16; i_++) if (t_acc[i_]) atomicAdd(&inf_time[i_], t_acc[i_]);
 #endif
         if (meta) { meta[c].out_bytes = err ? 0 : o; meta[c].ntok = 0; meta[c].adler_a = 1; meta[c].adler_b = 0; meta[c].in_bytes = 0; meta[c].data_type = 2; }
     }
@@ -644,7 +748,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
-        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(64), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
+        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
                            compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e));
         hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc);
         if (compact) {
