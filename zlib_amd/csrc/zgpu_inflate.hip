@@ -450,33 +450,47 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                 b.rd = pos >> 5; b.filled = uni(b.filled); b.seg_bits = uni(b.seg_bits);
                 stage_fill(b, L.stage, lane);
                 if (pos > b.seg_bits) { err = kMsgTruncated; break; }
-                uint32_t info, word; // info: bits 0-6 token length in bits (64 = not a token the walk may take)
+                // two windows of 64 bit offsets per step: lane i looks at offsets i and 64 + i
+                uint32_t info0, word0, info1, word1; // info: token length in bits (64 = not a token the walk may take)
                 {
                     const uint32_t p = pos + lane, wi = p >> 5, sh = p & 31;
-                    const uint32_t w0 = L.stage[wi & (kStageDwords - 1)], w1 = L.stage[(wi + 1) & (kStageDwords - 1)], w2 = L.stage[(wi + 2) & (kStageDwords - 1)];
-                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-                    const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
-                    const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
-                    const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
-                    const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
-                    const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
-                    const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
-                    const uint32_t dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
-                    const bool is_lit = e & kEntLit, is_match = e & ed & kEntLen;
-                    const uint32_t nb = is_lit ? l1 : t + l2 + xd;
-                    info = ((is_lit || is_match) && p + nb <= b.seg_bits) ? nb : 64u;
-                    word = is_lit ? (1u | ((e >> 16) << 2)) : (2u | (len << 2) | ((dist - 1) << 11));
+                    uint32_t w[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) w[k] = L.stage[(wi + k) & (kStageDwords - 1)];
+                    auto token_at = [&](uint32_t lo, uint32_t hi, uint32_t at, uint32_t &info, uint32_t &word) {
+                        const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
+                        const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
+                        const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
+                        const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
+                        const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
+                        const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
+                        const uint32_t dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
+                        const bool is_lit = e & kEntLit, is_match = e & ed & kEntLen;
+                        const uint32_t nb = is_lit ? l1 : t + l2 + xd;
+                        info = ((is_lit || is_match) && at + nb <= b.seg_bits) ? nb : 64u;
+                        word = is_lit ? (1u | ((e >> 16) << 2)) : (2u | (len << 2) | ((dist - 1) << 11));
+                    };
+                    token_at(__builtin_amdgcn_alignbit(w[1], w[0], sh), __builtin_amdgcn_alignbit(w[2], w[1], sh), p, info0, word0);
+                    token_at(__builtin_amdgcn_alignbit(w[3], w[2], sh), __builtin_amdgcn_alignbit(w[4], w[3], sh), p + 64, info1, word1);
                 }
                 INF_T(8);
                 // the walk: token starts from offset 0 on (a lane that is not a token is marked too and ends it)
-                uint64_t marks = 0;
+                uint64_t marks0 = 0, marks1 = 0;
                 uint32_t cur = 0;
-                do { marks |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info, (int)cur); } while (cur < 64);
-                const uint64_t bad = __ballot(info == 64u) & marks;
-                if (bad) { cur = (uint32_t)__builtin_ctzll(bad); marks &= (1ull << cur) - 1; }
+                do { marks0 |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info0, (int)cur); } while (cur < 64);
+                const uint64_t bad0 = __ballot(info0 == 64u) & marks0;
+                if (bad0) { cur = (uint32_t)__builtin_ctzll(bad0); marks0 &= (1ull << cur) - 1; }
+                else {
+                    uint32_t c1 = cur - 64;
+                    do { marks1 |= 1ull << c1; c1 += (uint32_t)__builtin_amdgcn_readlane((int)info1, (int)c1); } while (c1 < 64);
+                    const uint64_t bad1 = __ballot(info1 == 64u) & marks1;
+                    if (bad1) { c1 = (uint32_t)__builtin_ctzll(bad1); marks1 &= (1ull << c1) - 1; }
+                    cur = 64 + c1;
+                }
                 if (cur != 0) {
-                    emit_tokens(marks, word);
-                    INF_N(n_lit); // (rounds)
+                    emit_tokens(marks0, word0);
+                    if (marks1) emit_tokens(marks1, word1);
+                    INF_N(n_lit); // (steps)
                     INF_T(9);
                     pos += cur;
                     continue;

@@ -93,7 +93,7 @@ __host__ __device__ inline uint32_t crc_join(uint32_t cx, uint32_t cy, uint32_t 
 // (crc32.c:242-266 without the 4-byte variant: the table lives in LDS), then an 8-level tree of joins.
 __global__ void __launch_bounds__(256) crc_kernel(ChunkGeom g, ChunkMeta *meta)
 {
-    __shared__ uint32_t table[256];
+    __shared__ uint32_t table[4][256]; // table[k][b]: the CRC register after byte b and k more zero bytes (slicing by four, crc32.c:268-290)
     __shared__ uint32_t part[256];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     if (c >= g.nchunks) return;
@@ -106,15 +106,38 @@ __global__ void __launch_bounds__(256) crc_kernel(ChunkGeom g, ChunkMeta *meta)
         uint32_t r = tid;
 #pragma unroll
         for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ kCrcPoly : r >> 1;
-        table[tid] = r;
+        table[0][tid] = r;
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const uint32_t r = table[k - 1][tid];
+        table[k][tid] = (r >> 8) ^ table[0][r & 255u];
+        __syncthreads();
+    }
     const uint32_t L = (n + 255) / 256;
     const int64_t hi = (int64_t)n - (int64_t)(255 - tid) * L, lo_b = hi - L; // [lo_b, hi) clipped to [0, n)
     uint32_t crc = 0;
-    if (hi > 0) {
+    if (n == 65536 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // a full, aligned chunk: the lane's 256 bytes come in as sixteen 16-byte loads issued together, four bytes per step
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src + (size_t)tid * 256);
+        uint4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = s4[k];
         crc = 0xffffffffu;
-        for (int64_t i = lo_b > 0 ? lo_b : 0; i < hi; i++) crc = table[(crc ^ src[i]) & 255u] ^ (crc >> 8);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = crc ^ w[j];
+                crc = table[3][x & 255u] ^ table[2][(x >> 8) & 255u] ^ table[1][(x >> 16) & 255u] ^ table[0][x >> 24];
+            }
+        }
+        crc ^= 0xffffffffu;
+    } else if (hi > 0) {
+        crc = 0xffffffffu;
+        for (int64_t i = lo_b > 0 ? lo_b : 0; i < hi; i++) crc = table[0][(crc ^ src[i]) & 255u] ^ (crc >> 8);
         crc ^= 0xffffffffu;
     }
     part[tid] = crc;
