@@ -40,6 +40,25 @@ def test_inflate_oracle_streams(eng, level):
         assert eng.last_inflate.adler32 == O.adler32(data)
 
 
+def test_far_matches_between_literals(eng):
+    """Matches at distances close to the full 32 KiB window with fresh literals right behind them: the output ring in LDS is
+    exactly one window long, so a literal stored ahead of its turn would land on bytes such a match still has to read."""
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    parts, total = [base], len(base)
+    while total < 3 * 65536 + 12345:
+        back = int(rng.integers(32768 - 700, 32769))          # distance of the next copy
+        ln = int(rng.integers(3, 40))
+        flat = b"".join(parts)
+        parts = [flat, flat[len(flat) - back: len(flat) - back + ln], rng.integers(0, 256, int(rng.integers(1, 30)), dtype=np.uint8).tobytes()]
+        total = sum(len(x) for x in parts)
+    data = b"".join(parts)
+    for level in (1, 6, 9):
+        body, offs = oracle_stream(data, level)
+        out = eng.inflate_host(body, offs, out_len=len(data))
+        assert out == data, level
+
+
 @pytest.mark.parametrize("level", [1, 6, 9])
 def test_roundtrip_engine_to_engine(eng, level):
     data = CP.chunks(CP.KIND_SILESIA, 200, 48).tobytes()[: 48 * 65536 - 777]

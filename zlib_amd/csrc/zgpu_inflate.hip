@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
             uint32_t pos = consumed_bits(b); // the reader's position in bits from the segment's origin dword
             bool eob = false;
             while (!eob && !stop) {
-                pos = uni(pos);
+                pos = uni(pos); wr = uni(wr);
                 b.rd = pos >> 5; b.filled = uni(b.filled); b.seg_bits = uni(b.seg_bits);
                 stage_fill(b, L.stage, lane);
                 if (pos > b.seg_bits) { err = kMsgTruncated; break; }
@@ -457,21 +457,32 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                     uint32_t w[5];
 #pragma unroll
                     for (int k = 0; k < 5; k++) w[k] = L.stage[(wi + k) & (kStageDwords - 1)];
-                    auto token_at = [&](uint32_t lo, uint32_t hi, uint32_t at, uint32_t &info, uint32_t &word) {
-                        const uint32_t e = L.ltab[lo & ((1u << kLBits) - 1)];
-                        const uint32_t l1 = e & 15u, xl = (e >> 4) & 15u, t = l1 + xl;
-                        const uint32_t len = (e >> 16) + __builtin_amdgcn_ubfe(lo >> l1, 0, xl);
-                        const uint32_t h2 = (uint32_t)((((uint64_t)hi << 32) | lo) >> t);
-                        const uint32_t ed = L.dtab[h2 & ((1u << kDBits) - 1)];
-                        const uint32_t l2 = ed & 15u, xd = (ed >> 4) & 15u;
-                        const uint32_t dist = (ed >> 16) + __builtin_amdgcn_ubfe(h2 >> l2, 0, xd);
-                        const bool is_lit = e & kEntLit, is_match = e & ed & kEntLen;
-                        const uint32_t nb = is_lit ? l1 : t + l2 + xd;
-                        info = ((is_lit || is_match) && at + nb <= b.seg_bits) ? nb : 64u;
-                        word = is_lit ? (1u | ((e >> 16) << 2)) : (2u | (len << 2) | ((dist - 1) << 11));
-                    };
-                    token_at(__builtin_amdgcn_alignbit(w[1], w[0], sh), __builtin_amdgcn_alignbit(w[2], w[1], sh), p, info0, word0);
-                    token_at(__builtin_amdgcn_alignbit(w[3], w[2], sh), __builtin_amdgcn_alignbit(w[4], w[3], sh), p + 64, info1, word1);
+                    // (both windows side by side, so that their table lookups are in flight together)
+                    const uint32_t lo[2] = {__builtin_amdgcn_alignbit(w[1], w[0], sh), __builtin_amdgcn_alignbit(w[3], w[2], sh)};
+                    const uint32_t hi[2] = {__builtin_amdgcn_alignbit(w[2], w[1], sh), __builtin_amdgcn_alignbit(w[4], w[3], sh)};
+                    uint32_t e[2], ed[2], h2[2], t[2], len[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) e[k] = L.ltab[lo[k] & ((1u << kLBits) - 1)];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t l1 = e[k] & 15u, xl = (e[k] >> 4) & 15u;
+                        t[k] = l1 + xl;
+                        len[k] = (e[k] >> 16) + __builtin_amdgcn_ubfe(lo[k] >> l1, 0, xl);
+                        h2[k] = (uint32_t)((((uint64_t)hi[k] << 32) | lo[k]) >> t[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) ed[k] = L.dtab[h2[k] & ((1u << kDBits) - 1)];
+                    uint32_t info[2], word[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t l2 = ed[k] & 15u, xd = (ed[k] >> 4) & 15u;
+                        const uint32_t dist = (ed[k] >> 16) + __builtin_amdgcn_ubfe(h2[k] >> l2, 0, xd);
+                        const bool is_lit = e[k] & kEntLit, is_match = e[k] & ed[k] & kEntLen;
+                        const uint32_t nb = is_lit ? (e[k] & 15u) : t[k] + l2 + xd;
+                        info[k] = ((is_lit || is_match) && p + 64 * k + nb <= b.seg_bits) ? nb : 64u;
+                        word[k] = is_lit ? (1u | ((e[k] >> 16) << 2)) : (2u | (len[k] << 2) | ((dist - 1) << 11));
+                    }
+                    info0 = info[0]; word0 = word[0]; info1 = info[1]; word1 = word[1];
                 }
                 INF_T(8);
                 // the walk: token starts from offset 0 on (a lane that is not a token is marked too and ends it)
