@@ -196,12 +196,18 @@ def main():
                 if (a.op == "deflate" and dom == "match" and a.level == 6 and a.workload == "silesia-mix" and abs(nbytes / 2**30 - 4.0) < 1e-9
                         and a.lz in ("auto", "sorted")):
                     traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_final_traffic.json"
+                if a.op == "inflate" and dom == "inflate" and a.level == 6 and a.workload == "silesia-mix" and abs(nbytes / 2**30 - 4.0) < 1e-9:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_inflate_traffic.json")))
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_inflate_traffic.json"
             except (OSError, ValueError, KeyError):
                 pass
+            limiter = {"match": "VALU issue (78-84 % of the vector-ALU peak, rocprofv3 PMC in profiles/); not HBM",
+                       "inflate": "latency of the per-token chains of one reader and one writer wave per segment, four segments per CU "
+                                  "(32 KiB LDS ring each); vector and scalar pipes 25-28 % busy (profiles/r01_inflate_4gib_L6_summary.txt); not HBM"}.get(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                    "limiter": "VALU issue (78-84 % of the vector-ALU peak, rocprofv3 PMC in profiles/); not HBM" if dom == "match" else None,
+                    "limiter": limiter,
                     "avg_launch_ms": round(ms / launches, 4), "launches": launches,
                     "stage_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in stages.items()}}
         line = {
