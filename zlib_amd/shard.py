@@ -54,7 +54,9 @@ def gather_stream(body: torch.Tensor, adler: int, in_bytes: int, level: int, out
     sizes = [r[0] for r in rows]
     total = 2 + sum(sizes) + 4
     if rank != 0:
-        dist.send(body, dst=0, group=group)
+        if body.numel():
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, body, 0, group)]):
+                q.wait()
         return None, total
     if out is None or out.numel() < total:
         out = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -62,11 +64,14 @@ def gather_stream(body: torch.Tensor, adler: int, in_bytes: int, level: int, out
     off = 2
     out[off:off + sizes[0]].copy_(body)
     off += sizes[0]
-    reqs = []
+    # one coalesced group of receives (ncclGroupStart/End under RCCL): posted one by one they would run one after the
+    # other on the communicator's stream, and the peers' links would take turns instead of running side by side
+    ops = []
     for r in range(1, world):
-        reqs.append(dist.irecv(out[off:off + sizes[r]], src=r, group=group))
+        if sizes[r]:
+            ops.append(dist.P2POp(dist.irecv, out[off:off + sizes[r]], r, group))
         off += sizes[r]
-    for q in reqs:
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
         q.wait()
     a = 1
     for r in range(world):
