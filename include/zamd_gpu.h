@@ -131,7 +131,12 @@ int zgpu_deflate_dict_chunk_host(zgpu_engine *e, const void *window, uint32_t wi
  * chunk_size bytes, written at d_out + k*chunk_size (every segment but the last must decode to exactly
  * chunk_size bytes).  chunk_size == 0 selects "compact" mode: segments of any size up to 65536 bytes are
  * decoded and their outputs concatenated (streams that were flushed in the middle of a chunk).  The last
- * segment must end with a final block; the others end with a stored empty block (flush marker). */
+ * segment must end with a final block; the others end with a stored empty block (flush marker).
+ * chunk_size == ZGPU_WHOLE_STREAM with nchunks == 1: the one segment is a complete raw-deflate stream of any size
+ * (< 512 MiB compressed, < 4 GiB decoded) that was not produced in chunks; one workgroup decodes it from end to end
+ * (inflate.c:773-1076 + inffast.c:67-302 as they run for any stream).  When out_cap is too small the call returns
+ * ZGPU_BUF_ERROR with res->out_bytes = the size the stream decodes to. */
+#define ZGPU_WHOLE_STREAM 0xFFFFFFFFu
 int zgpu_inflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const uint64_t *d_chunk_offsets,
                         uint64_t nchunks, uint32_t chunk_size, void *d_out, uint64_t out_cap,
                         zgpu_inflate_result *res, void *hip_stream);
@@ -143,7 +148,8 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
  * header).  Returns ZGPU_OK and *nchunks, or ZGPU_DATA_ERROR when no consistent split exists. */
 int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size,
                                   uint64_t *offsets, uint64_t max_chunks, uint64_t *nchunks);
-/* The same search, delivering the decoded bytes: raw deflate body in (no zlib header / trailer), bytes out. */
+/* The same search, delivering the decoded bytes: raw deflate body in (no zlib header / trailer), bytes out.  A body
+ * that does not split into independent segments (any other producer's stream) is decoded as ZGPU_WHOLE_STREAM. */
 int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap,
                              zgpu_inflate_result *res);
 const char *zgpu_inflate_message(uint32_t index);

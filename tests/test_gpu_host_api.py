@@ -154,6 +154,37 @@ def test_foreign_single_segment_stream():
     assert rc == 0 and back == tricky
 
 
+def test_foreign_streams_of_any_size():
+    """Streams of another producer (here the system zlib): matches reach across 64 KiB, no full-flush markers, or markers of
+    Z_SYNC_FLUSH that do not reset the window.  They do not split into independent segments; one workgroup decodes them from
+    end to end (ZGPU_WHOLE_STREAM) and inflate()/uncompress() deliver the same bytes as for any other stream."""
+    import zlib
+    data = cases.make("mix", 700000, 9)
+    for level in (1, 6, 9):
+        z = zlib.compress(data, level)
+        rc, back = Z.uncompress(z, len(data))
+        assert rc == 0 and back == data, level
+    # sync-flush markers in the middle (the window is kept: the pieces depend on each other)
+    co = zlib.compressobj(6)
+    z = co.compress(data[:100000]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(data[100000:300000]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(data[300000:]) + co.flush()
+    rc, back = Z.uncompress(z, len(data))
+    assert rc == 0 and back == data
+    # a gzip member, fed in pieces, output drained in pieces
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = co.compress(data) + co.flush()
+    rc, back, _, _ = Z.inflate_stream(gz, len(data), in_step=50000, out_step=30000, window_bits=47)
+    assert rc == Z.Z_STREAM_END and back == data
+    # destination too small: Z_BUF_ERROR like the reference's uncompress (uncompr.c:53-57)
+    rc, _ = Z.uncompress(zlib.compress(data, 6), len(data) - 1)
+    assert rc == Z.Z_BUF_ERROR
+    # damage in the middle of the stream: a data error, as the system zlib finds one too
+    bad = bytearray(zlib.compress(data, 6)); bad[len(bad) // 2] ^= 0x55
+    with pytest.raises(zlib.error):
+        zlib.decompress(bytes(bad))
+    rc, _ = Z.uncompress(bytes(bad), len(data))
+    assert rc == Z.Z_DATA_ERROR
+
+
 def test_level0_block_structure():
     """deflate_stored's cuts (deflate.c:1390-1439) for chunk lengths around MAX_DIST and the 65531-byte block limit, finished or
     flushed: the host library's framing against the oracle (which is pinned to the reference for level 0)."""

@@ -40,6 +40,42 @@ def test_inflate_oracle_streams(eng, level):
         assert eng.last_inflate.adler32 == O.adler32(data)
 
 
+def test_whole_stream_segment(eng):
+    """chunk_size ZGPU_WHOLE_STREAM: one raw-deflate stream of any size as a single segment (system zlib as the producer);
+    a destination that is too small gets ZGPU_BUF_ERROR and the size that was needed."""
+    import zlib
+    import zlib_amd
+    from zlib_amd import gpu
+    data = cases.make("mix", 400000, 3) + bytes(200000) + cases.make("rand", 70000, 4)
+    for level in (0, 1, 6, 9):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = co.compress(data) + co.flush()
+        offs = np.array([0, len(raw)], dtype=np.uint64)
+        out = eng.inflate_host(raw, offs, chunk_size=gpu.WHOLE_STREAM, out_len=len(data))
+        assert out == data, level
+        assert eng.last_inflate.adler32 == O.adler32(data)
+    with pytest.raises(zlib_amd.EngineError) as ei:
+        eng.inflate_host(raw, offs, chunk_size=gpu.WHOLE_STREAM, out_len=len(data) - 5)
+    assert ei.value.code == -5 and eng.last_inflate.out_bytes == len(data)
+
+
+def test_whole_stream_many_alignments(eng):
+    """Many streams of assorted sizes, contents and levels through the end-to-end decoder: block boundaries, input-ring refills
+    and token hand-overs fall on ever different alignments (a refill that ran two dwords too far showed up once in thousands
+    of blocks)."""
+    import zlib
+    from zlib_amd import gpu
+    rng = np.random.default_rng(2024)
+    kinds = ("mix", "text", "rand", "ab")
+    for i in range(36):
+        n = int(rng.integers(150000, 900000))
+        data = cases.make(kinds[i % 4], n, 100 + i) if i % 4 != 2 else cases.make("text", n // 2, 100 + i) + cases.make("rand", n // 2, i)
+        co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15)
+        raw = co.compress(data) + co.flush()
+        out = eng.inflate_host(raw, np.array([0, len(raw)], dtype=np.uint64), chunk_size=gpu.WHOLE_STREAM, out_len=len(data))
+        assert out == data, (i, n)
+
+
 def test_far_matches_between_literals(eng):
     """Matches at distances close to the full 32 KiB window with fresh literals right behind them: the output ring in LDS is
     exactly one window long, so a literal stored ahead of its turn would land on bytes such a match still has to read."""

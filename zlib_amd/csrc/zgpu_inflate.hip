@@ -115,8 +115,10 @@ __device__ inline void settle(BitSrc &b) // (the compiler cannot see that loop-c
 
 __device__ inline void stage_fill(BitSrc &b, uint32_t *stage, uint32_t lane)
 {
-    // keep at least 128 dwords ahead of the reader; each call loads 128 dwords (8 bytes per lane)
-    while (b.filled - b.rd < 128) {
+    // keep at least 120 dwords ahead of the reader; each call loads 128 dwords (8 bytes per lane).  The ring holds 256: the
+    // scalar reader's rd runs two dwords ahead of the position it will be set back to (reposition, the lane-parallel decode),
+    // so a fill must leave room behind rd as well: 119 + 128 ahead at most, 9 behind at least.
+    while (b.filled - b.rd < 120) {
         const uint64_t i = b.d0 + b.filled + lane * 2;
         uint32_t v[2];
 #pragma unroll
@@ -266,6 +268,7 @@ __device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t t
 //   command: bits 2-3 which (1 stored bytes: bits 4-20 count, the next two words = offset of the bytes in the input;
 //            2 end of the segment: bits 4-11 the reader's verdict)
 enum : uint32_t { kCmdStored = 1, kCmdEnd = 2 };
+constexpr uint32_t kWholeStream = 0xFFFFFFFFu; // chunk_size argument: the one segment is a whole stream of any size
 
 __device__ inline void block_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
@@ -284,7 +287,11 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
     // chunk_size_arg == 0: "compact" mode, segments of any size up to 64 KiB are decoded into per-chunk slots and
     // concatenated afterwards (used for streams whose chunks are not all full, e.g. flushed mid-chunk)
     const bool compact = chunk_size_arg == 0;
-    const uint32_t chunk_size = compact ? kChunkMax : chunk_size_arg;
+    // chunk_size_arg == kWholeStream: one segment of any size (a stream that was not produced in chunks): decoded from end to
+    // end by this one workgroup straight into the destination, limited only by the destination's capacity (a destination
+    // that is too small still gets the size that would have been needed)
+    const bool whole = chunk_size_arg == kWholeStream;
+    const uint32_t chunk_size = compact ? kChunkMax : whole ? 0xFFFF0000u : chunk_size_arg;
     // a preset dictionary (inflateSetDictionary, inflate.c:1200-1236) is what the window holds before the first byte: in the ring it
     // sits right below position 0, and the first segment may reach that much farther back
     const uint32_t reach = (gc == 0) ? dict_len : 0u;
@@ -572,8 +579,8 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
     for (uint32_t i = lane; i < reach; i += 64) L.out[(kOutRing - reach + i) & (kOutRing - 1)] = dict[i];
     uint32_t flushed = 0; // bytes already copied from the LDS ring to the destination (a multiple of kOutHalf until the end)
     bool nofit = false;   // direct placement: the destination ended before the chunk did
-    uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : out + gc * (uint64_t)chunk_size;
-    const uint64_t dst_room = compact ? kChunkMax : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
+    uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : whole ? out : out + gc * (uint64_t)chunk_size;
+    const uint64_t dst_room = compact ? kChunkMax : whole ? out_cap : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
     // copy a match of `len` bytes at distance `dist` to output position `at`; a distance shorter than the length repeats its
     // pattern (byte-sequential semantics of inffast.c:246-259).  The ring holds the last 32 KiB: a read at the full distance
     // 32768 hits the slot its own lane is about to write.
@@ -749,7 +756,8 @@ struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
 {
-    if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || chunk_size > kChunkMax)
+    if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || (chunk_size > kChunkMax && !(chunk_size == kWholeStream && nchunks == 1)) ||
+        (chunk_size == kWholeStream && in_bytes >= (1ull << 29)))
         return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
     const bool compact = chunk_size == 0; // segments of any size: decode into slots, then concatenate
@@ -865,8 +873,19 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st);
         if (rc == ZGPU_OK) break;
-        if (rc != ZGPU_DATA_ERROR || res->first_bad_chunk < 0 || (uint64_t)res->first_bad_chunk + 1 >= nseg) return rc;
-        b.erase(b.begin() + res->first_bad_chunk + 1); // not a boundary after all: merge with the next segment
+        if (rc == ZGPU_DATA_ERROR && res->first_bad_chunk >= 0 && (uint64_t)res->first_bad_chunk + 1 < nseg) {
+            b.erase(b.begin() + res->first_bad_chunk + 1); // not a boundary after all: merge with the next segment
+            continue;
+        }
+        // The last segment does not decode on its own.  A body that simply stops early is reported as such; anything else may
+        // be a stream that was not produced in independent chunks (segments longer than 64 KiB, distances that reach back
+        // across what looked like a boundary): one workgroup decodes it from end to end, and its verdict is the stream's.
+        if (rc != ZGPU_DATA_ERROR || res->error_msg == kMsgTruncated || in_bytes >= (1ull << 29)) return rc;
+        b.assign({0, in_bytes});
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        rc = inflate_run(e, d_in, in_bytes, d_offs, 1, kWholeStream, engine_stage_out(e), out_cap, res, st);
+        if (rc != ZGPU_OK) return rc;
+        break;
     }
     if (out && res->out_bytes) ZGPU_HIP_CHECK(hipMemcpy(out, engine_stage_out(e), res->out_bytes, hipMemcpyDeviceToHost));
     if (offsets_out) *offsets_out = b;

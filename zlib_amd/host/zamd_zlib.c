@@ -558,12 +558,13 @@ static int decode_all(z_streamp strm, size_t out_hint)
         s->out.len = 0; s->out_pos = 0;
         if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
         zgpu_inflate_result r;
+        memset(&r, 0, sizeof r);
         pthread_mutex_lock(&g_lock);
         int rc = zgpu_inflate_set_dictionary(e, s->have_dict ? s->dict.p : NULL, s->have_dict ? (uint32_t)s->dict.len : 0u);
         if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host(e, p + skip, body, s->out.p, cap, &r);
         if (s->have_dict) zgpu_inflate_set_dictionary(e, NULL, 0);
         pthread_mutex_unlock(&g_lock);
-        if (rc == ZGPU_BUF_ERROR) { cap *= 4; if (cap > ((size_t)1 << 40)) return Z_MEM_ERROR; continue; }
+        if (rc == ZGPU_BUF_ERROR) { cap = r.out_bytes > cap ? (size_t)r.out_bytes : cap * 4; if (cap > ((size_t)1 << 40)) return Z_MEM_ERROR; continue; }
         if (rc == ZGPU_DATA_ERROR) {
             /* a body that stops inside a block is what a not-yet-complete stream looks like */
             const char *m = zgpu_inflate_message(r.error_msg);
