@@ -141,6 +141,9 @@ __device__ inline uint32_t consumed_bits(const BitSrc &b) { return b.rd * 32 - b
 // one wave's LDS operations complete in order: ordering its own writes and reads needs the compiler held back, no barrier
 __device__ inline void wave_sync() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// set bit i of a wave-uniform mask (one scalar instruction; the shift-and-or the compiler emits is two in the walk's chain)
+__device__ inline void mark_bit(uint64_t &m, uint32_t i) { asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(i)); }
+
 // v = the lane's bit of a wave mask ? a : b
 __device__ inline uint32_t sel_mask(uint64_t m, uint32_t a, uint32_t b)
 {
@@ -495,12 +498,12 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                 // the walk: token starts from offset 0 on (a lane that is not a token is marked too and ends it)
                 uint64_t marks0 = 0, marks1 = 0;
                 uint32_t cur = 0;
-                do { marks0 |= 1ull << cur; cur += (uint32_t)__builtin_amdgcn_readlane((int)info0, (int)cur); } while (cur < 64);
+                do { mark_bit(marks0, cur); cur += (uint32_t)__builtin_amdgcn_readlane((int)info0, (int)cur); } while (cur < 64);
                 const uint64_t bad0 = __ballot(info0 == 64u) & marks0;
                 if (bad0) { cur = (uint32_t)__builtin_ctzll(bad0); marks0 &= (1ull << cur) - 1; }
                 else {
                     uint32_t c1 = cur - 64;
-                    do { marks1 |= 1ull << c1; c1 += (uint32_t)__builtin_amdgcn_readlane((int)info1, (int)c1); } while (c1 < 64);
+                    do { mark_bit(marks1, c1); c1 += (uint32_t)__builtin_amdgcn_readlane((int)info1, (int)c1); } while (c1 < 64);
                     const uint64_t bad1 = __ballot(info1 == 64u) & marks1;
                     if (bad1) { c1 = (uint32_t)__builtin_ctzll(bad1); marks1 &= (1ull << c1) - 1; }
                     cur = 64 + c1;
