@@ -487,10 +487,13 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                     for (int k = 0; k < 2; k++) {
                         const uint32_t l2 = ed[k] & 15u, xd = (ed[k] >> 4) & 15u;
                         const uint32_t dist = (ed[k] >> 16) + __builtin_amdgcn_ubfe(h2[k] >> l2, 0, xd);
-                        const bool is_lit = e[k] & kEntLit, is_match = e[k] & ed[k] & kEntLen;
-                        const uint32_t nb = is_lit ? (e[k] & 15u) : t[k] + l2 + xd;
-                        info[k] = ((is_lit || is_match) && p + 64 * k + nb <= b.seg_bits) ? nb : 64u;
-                        word[k] = is_lit ? (1u | ((e[k] >> 16) << 2)) : (2u | (len[k] << 2) | ((dist - 1) << 11));
+                        // (selects by mask arithmetic: written as ?: the compiler turns the two token kinds into branches on exec)
+                        const uint32_t litm = 0u - ((e[k] >> 8) & 1u), l1 = e[k] & 15u;
+                        const uint32_t tokm = litm | (0u - ((e[k] & ed[k] & kEntLen) >> 10));
+                        const uint32_t nb = l1 + ((t[k] - l1 + l2 + xd) & ~litm);
+                        const uint32_t as_lit = 1u | ((e[k] >> 16) << 2), as_match = 2u | (len[k] << 2) | ((dist - 1) << 11);
+                        word[k] = (as_lit & litm) | (as_match & ~litm);
+                        info[k] = (tokm != 0 && p + 64 * k + nb <= b.seg_bits) ? nb : 64u;
                     }
                     info0 = info[0]; word0 = word[0]; info1 = info[1]; word1 = word[1];
                 }
