@@ -68,6 +68,9 @@ struct ParseCtx {
     }
 };
 
+// lane i <- lane (i + 1) mod 64
+__device__ inline uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xf, 0xf, false); }
+
 __device__ inline uint32_t next_bit(const uint32_t *bits, uint32_t x, uint32_t nwords) // smallest set bit index >= x, or kNone
 {
     uint32_t w = x >> 5;
@@ -173,12 +176,17 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
                     uint32_t L = kMinMatch - 1, D = 0, j = 1; // the match in hand starts at p + j - 1
                     if (hs) L = cx.take(p, kMinMatch - 1, ra[u], D);
                     bool live = hs;
-                    while (__builtin_amdgcn_ballot_w64(live)) { // all lanes shuffle, the ones in a game use the result
+                    // the games of a wave advance in step (j is the same in every lane that is still playing), so the records
+                    // they need next are the wave's records rotated by one more lane each time: a DPP rotate per register, the
+                    // overhang entering at lane 63 (a lane shuffle through the LDS crossbar per step was the cost of this loop)
+                    uint32_t qx = ra[u].x, qy = ra[u].y, ox = rx[u].x, oy = rx[u].y;
+                    while (__builtin_amdgcn_ballot_w64(live)) {
                         const uint32_t sl = lane + j;
+                        const uint32_t tx = wave_rol1(qx), ty = wave_rol1(qy);
+                        ox = wave_rol1(ox); oy = wave_rol1(oy);
+                        qx = lane == 63 ? ox : tx; qy = lane == 63 ? oy : ty;
                         uint2 rn;
-                        const uint32_t ax = (uint32_t)__shfl((int)ra[u].x, (int)(sl & 63u)), ay = (uint32_t)__shfl((int)ra[u].y, (int)(sl & 63u));
-                        const uint32_t bx = (uint32_t)__shfl((int)rx[u].x, (int)(sl & 63u)), by = (uint32_t)__shfl((int)rx[u].y, (int)(sl & 63u));
-                        rn.x = sl < 64 ? ax : bx; rn.y = sl < 64 ? ay : by;
+                        rn.x = qx; rn.y = qy;
                         if (live) {
                             if (sl >= 64 + kP2Over) rn = cx.rec[p + j]; // a game that long is rare
                             uint32_t D2 = 0;
