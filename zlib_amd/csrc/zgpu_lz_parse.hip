@@ -40,15 +40,15 @@ struct ParseCtx {
     // the match the loop takes at p when the match in hand has length prev_len (deflate.c:1585-1606); 2 = none
     __device__ uint32_t take(uint32_t p, uint32_t prev_len, uint2 r, uint32_t &dist) const
     {
-        if (prev_len >= lazy) return kMinMatch - 1;
+        // (one straight line of selects: written with early returns this becomes a ladder of exec-mask branches in every caller)
         const uint32_t pick = (prev_len >= good && strategy != kRle) ? r.y : r.x; // (longest_match_fast has no chain to shorten)
-        uint32_t len = pick & 511u;
         const uint32_t d = (pick >> 9) & 32767u;
-        if (((r.y >> 24) & 1u) && slid(p)) len = 0; // first candidate became NIL in the slide
-        if (len <= prev_len) return kMinMatch - 1;
-        if (len <= 5 && (strategy == kFiltered || (len == kMinMatch && d > kTooFar))) return kMinMatch - 1; // deflate.c:1601-1611
-        dist = d;
-        return len;
+        const bool nil = ((r.y >> 24) & 1u) && slid(p);                            // first candidate became NIL in the slide
+        const uint32_t len = nil ? 0u : (pick & 511u);
+        const bool weak = len <= 5 && (strategy == kFiltered || (len == kMinMatch && d > kTooFar)); // deflate.c:1601-1611
+        const bool ok = prev_len < lazy && len > prev_len && !weak;
+        dist = ok ? d : dist;
+        return ok ? len : kMinMatch - 1;
     }
     // the lazy-evaluation game from a has-position r: match start m, length, distance.  rr = rec[r], rn = rec[r+1] (callers load
     // them in batches: one load latency per position would otherwise be the whole cost of this kernel)
@@ -187,12 +187,12 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
                         qx = lane == 63 ? ox : tx; qy = lane == 63 ? oy : ty;
                         uint2 rn;
                         rn.x = qx; rn.y = qy;
-                        if (live) {
-                            if (sl >= 64 + kP2Over) rn = cx.rec[p + j]; // a game that long is rare
-                            uint32_t D2 = 0;
-                            const uint32_t L2 = cx.take(p + j, L, rn, D2);
-                            if (L2 <= L) live = false; else { L = L2; D = D2; j++; }
-                        }
+                        const bool far = live && sl >= 64 + kP2Over;
+                        if (__builtin_amdgcn_ballot_w64(far)) { if (far) rn = cx.rec[p + j]; } // a game that long is rare
+                        uint32_t D2 = D;
+                        const uint32_t L2 = cx.take(p + j, L, rn, D2); // (pure arithmetic: every lane evaluates it, the ones in a game use it)
+                        live = live && L2 > L;
+                        L = live ? L2 : L; D = live ? D2 : D; j += live ? 1u : 0u;
                     }
                     uint32_t succ = 0xffffu;
                     if (hs) {
