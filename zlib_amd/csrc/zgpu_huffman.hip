@@ -192,20 +192,39 @@ __device__ void walk_lengths(const uint8_t *len, int max_code, uint16_t *blfreq,
     }
 }
 
+// Length and distance codes in closed form (the maps behind _length_code / _dist_code / base_length / base_dist / extra_lbits /
+// extra_dbits of trees.h and trees.c:61-68): code and number of extra bits from the position of the leading one; the extra
+// bits' value is the low bits of the length or distance itself, because every code's base is a multiple of its range.
+// Per-lane lookups in constant memory cost a vector-memory round trip each, six of them per match token.
+__device__ inline void len_code_of(uint32_t lc, uint32_t &code, uint32_t &extra) // lc = match length - 3
+{
+    const uint32_t e = (31u - (uint32_t)__clz((int)(lc | 8u))) - 2u; // 1..5 for lc >= 8
+    const bool small = lc < 8, top = lc == 255;                       // length 258 has its own code without extra bits
+    code = small ? lc : top ? 28u : 4u * e + 4u + ((lc >> e) & 3u);
+    extra = (small || top) ? 0u : e;
+}
+__device__ inline void dist_code_bits(uint32_t d, uint32_t &code, uint32_t &extra) // d = match distance - 1
+{
+    const uint32_t msb = 31u - (uint32_t)__clz((int)(d | 2u));
+    const bool small = d < 4;
+    code = small ? d : 2u * msb + ((d >> (msb - 1u)) & 1u);
+    extra = small ? 0u : msb - 1u;
+}
+
 __device__ inline void token_bits(uint32_t t, const uint16_t *lcode, const uint8_t *llen, const uint16_t *dcode, const uint8_t *dlen,
                                   uint64_t &bits, uint32_t &nb)
 {
     uint32_t dist = t >> 8, lc = t & 255;
     if (dist == 0) { bits = lcode[lc]; nb = llen[lc]; return; }
-    uint32_t c = kTables.len_code[lc], s = 257 + c;
+    uint32_t c, xl, dc, xd;
+    len_code_of(lc, c, xl);
+    const uint32_t s = 257 + c;
     bits = lcode[s]; nb = llen[s];
-    const uint32_t xl = kTables.xl[c];
-    if (xl) { bits |= (uint64_t)(lc - kTables.base_len[c]) << nb; nb += xl; } // length 258 (code 28) has base 0 and no extra bits
+    bits |= (uint64_t)(lc & ((1u << xl) - 1u)) << nb; nb += xl;
     dist--;
-    uint32_t dc = dist_code_of(dist);
+    dist_code_bits(dist, dc, xd);
     bits |= (uint64_t)dcode[dc] << nb; nb += dlen[dc];
-    const uint32_t xd = kTables.xd[dc];
-    if (xd) { bits |= (uint64_t)(dist - kTables.base_dist[dc]) << nb; nb += xd; }
+    bits |= (uint64_t)(dist & ((1u << xd) - 1u)) << nb; nb += xd;
 }
 
 __device__ inline uint32_t block_reduce_add(uint32_t v, uint32_t *tmp)
@@ -270,7 +289,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         for (uint32_t i = t0 + tid; i < t1; i += kThreads) {
             uint32_t t = tok[i], dist = t >> 8, lc = t & 255;
             if (dist == 0) { atomicAdd(&hist[lc], 1u); bytes += 1; }
-            else { atomicAdd(&hist[257 + kTables.len_code[lc]], 1u); atomicAdd(&hist[kLCodes + dist_code_of(dist - 1)], 1u); bytes += lc + 3; }
+            else { uint32_t c, xl, dc, xd; len_code_of(lc, c, xl); dist_code_bits(dist - 1, dc, xd); atomicAdd(&hist[257 + c], 1u); atomicAdd(&hist[kLCodes + dc], 1u); bytes += lc + 3; }
         }
         const uint32_t stored_len = block_reduce_add(bytes, tmp);
         __syncthreads();
