@@ -39,6 +39,7 @@ struct TreeWorkT {
     uint16_t len[kNodes];
     __attribute__((aligned(8))) uint32_t heap[kNodes + 1]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order
     uint16_t bl_count[kMaxBits + 1];
+    uint16_t next_code[kMaxBits + 1];
 };
 using TreeWork = TreeWorkT<kHeapSize>;          // literal/length tree, and the bit-length tree after it
 using TreeWorkD = TreeWorkT<2 * kDCodes + 1>;    // distance tree: a tenth of the LDS, so more chunks are resident per CU
@@ -89,10 +90,22 @@ __device__ inline void sift_down(TW &t, int heap_len, int k) // pqdownheap, tree
 // slen: static code lengths (constant memory) or nullptr; xbits/xbase: extra-bit table and first symbol using it.
 // Results: out_len / out_code for symbols 0..elems-1; returns max_code.  opt_len / static_len accumulate mod 2^32
 // exactly like the reference's unsigned long arithmetic does mod 2^64 (the transient "-1" of the forced codes).
+// extra bits and static code length of symbol n of tree `kind` (0 literal/length, 1 distance, 2 bit lengths), in closed form
+// (extra_lbits / extra_dbits / extra_blbits, trees.c:61-68; static_ltree lengths, trees.c:251-262; static distances are 5 bits):
+// the serial lane would otherwise wait for a constant-memory load per symbol
+__device__ inline uint32_t extra_bits_of(int kind, int n)
+{
+    if (kind == 0) { const int k = n - 257; return (k < 8 || k == 28) ? 0u : (uint32_t)((k >> 2) - 1); }
+    if (kind == 1) return n < 4 ? 0u : (uint32_t)((n >> 1) - 1);
+    return n == 16 ? 2u : n == 17 ? 3u : n == 18 ? 7u : 0u;
+}
+__device__ inline uint32_t static_len_of(int kind, int n) { return kind == 0 ? (n < 144 ? 8u : n < 256 ? 9u : n < 280 ? 7u : 8u) : 5u; }
+
 template <class TW>
-__device__ int build_tree(TW &t, int elems, const uint8_t *slen, const uint8_t *xbits, int xbase, int max_length,
+__device__ int build_tree(TW &t, int elems, int kind, int max_length,
                           uint16_t *out_code, uint8_t *out_len, uint32_t &opt_len, uint32_t &static_len)
 {
+    const bool has_static = kind != 2;
     int heap_len = 0, heap_max = TW::kCap, max_code = -1, n, m, node;
     for (n = 0; n < elems; n++) {
         if (t.freq[n] != 0) t.heap[++heap_len] = heap_entry(t.freq[n], 0, (uint32_t)(max_code = n));
@@ -102,7 +115,7 @@ __device__ int build_tree(TW &t, int elems, const uint8_t *slen, const uint8_t *
         node = max_code < 2 ? ++max_code : 0;
         t.heap[++heap_len] = heap_entry(1, 0, (uint32_t)node);
         t.freq[node] = 1; opt_len--;
-        if (slen) static_len -= slen[node];
+        if (has_static) static_len -= static_len_of(kind, node);
     }
     for (n = heap_len / 2; n >= 1; n--) sift_down(t, heap_len, n);
     node = elems;
@@ -130,9 +143,9 @@ __device__ int build_tree(TW &t, int elems, const uint8_t *slen, const uint8_t *
         t.len[n] = (uint16_t)bits;
         if (n > max_code) continue;
         t.bl_count[bits]++;
-        int xb = (n >= xbase) ? xbits[n - xbase] : 0;
-        opt_len += (uint32_t)t.freq[n] * (uint32_t)(bits + xb);
-        if (slen) static_len += (uint32_t)t.freq[n] * (uint32_t)(slen[n] + xb);
+        const uint32_t xb = (kind != 0 || n >= 257) ? extra_bits_of(kind, n) : 0u;
+        opt_len += (uint32_t)t.freq[n] * ((uint32_t)bits + xb);
+        if (has_static) static_len += (uint32_t)t.freq[n] * (static_len_of(kind, n) + xb);
     }
     if (overflow > 0) {
         do {
@@ -155,19 +168,21 @@ __device__ int build_tree(TW &t, int elems, const uint8_t *slen, const uint8_t *
         }
     }
     // gen_codes
-    uint32_t next[kMaxBits + 1], c = 0;
-    for (bits = 1; bits <= kMaxBits; bits++) { c = (c + t.bl_count[bits - 1]) << 1; next[bits] = c; }
+    uint32_t c = 0; // (next_code in LDS: a private array indexed by a code length would live in scratch memory)
+    for (bits = 1; bits <= kMaxBits; bits++) { c = (c + t.bl_count[bits - 1]) << 1; t.next_code[bits] = (uint16_t)c; }
     for (n = 0; n < elems; n++) {
         int l = (n <= max_code) ? t.len[n] : 0;
         out_len[n] = (uint8_t)l;
-        out_code[n] = l ? (uint16_t)(__brev(next[l]++) >> (32 - l)) : 0;
+        out_code[n] = l ? (uint16_t)(__brev((uint32_t)t.next_code[l]++) >> (32 - l)) : 0;
     }
     return max_code;
 }
 
-// scan_tree (emit == nullptr: count into blfreq) / send_tree (emit != nullptr), trees.c:707-797
-__device__ void walk_lengths(const uint8_t *len, int max_code, uint16_t *blfreq, BitWriter *emit, const uint16_t *blcode,
-                             const uint8_t *bllen)
+// scan_tree (kEmit false: count into blfreq) / send_tree (kEmit true), trees.c:707-797.  Inlined, the writer by reference: a
+// writer whose address is passed to a real call lives in scratch memory, and every put() is then a trip to HBM and back.
+template <bool kEmit>
+__device__ __forceinline__ void walk_lengths(const uint8_t *len, int max_code, uint16_t *blfreq, BitWriter &bw, const uint16_t *blcode,
+                                             const uint8_t *bllen)
 {
     int prevlen = -1, curlen, nextlen = len[0], count = 0, max_count = 7, min_count = 4;
     if (nextlen == 0) { max_count = 138; min_count = 3; }
@@ -175,15 +190,15 @@ __device__ void walk_lengths(const uint8_t *len, int max_code, uint16_t *blfreq,
         curlen = nextlen; nextlen = (n == max_code) ? 0xffff : len[n + 1];
         if (++count < max_count && curlen == nextlen) continue;
         else if (count < min_count) {
-            if (emit) { do { emit->put(blcode[curlen], bllen[curlen]); } while (--count != 0); }
+            if (kEmit) { do { bw.put(blcode[curlen], bllen[curlen]); } while (--count != 0); }
             else blfreq[curlen] += (uint16_t)count;
         } else if (curlen != 0) {
-            if (curlen != prevlen) { if (emit) { emit->put(blcode[curlen], bllen[curlen]); count--; } else blfreq[curlen]++; }
-            if (emit) { emit->put(blcode[16], bllen[16]); emit->put((uint32_t)(count - 3), 2); } else blfreq[16]++;
+            if (curlen != prevlen) { if (kEmit) { bw.put(blcode[curlen], bllen[curlen]); count--; } else blfreq[curlen]++; }
+            if (kEmit) { bw.put(blcode[16], bllen[16]); bw.put((uint32_t)(count - 3), 2); } else blfreq[16]++;
         } else if (count <= 10) {
-            if (emit) { emit->put(blcode[17], bllen[17]); emit->put((uint32_t)(count - 3), 3); } else blfreq[17]++;
+            if (kEmit) { bw.put(blcode[17], bllen[17]); bw.put((uint32_t)(count - 3), 3); } else blfreq[17]++;
         } else {
-            if (emit) { emit->put(blcode[18], bllen[18]); emit->put((uint32_t)(count - 11), 7); } else blfreq[18]++;
+            if (kEmit) { bw.put(blcode[18], bllen[18]); bw.put((uint32_t)(count - 11), 7); } else blfreq[18]++;
         }
         count = 0; prevlen = curlen;
         if (nextlen == 0) { max_count = 138; min_count = 3; }
@@ -262,7 +277,6 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
     __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
     __shared__ uint32_t tmp[4];
-    __shared__ uint8_t five[kDCodes];
     __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
     __shared__ uint64_t sh_bitpos;
 
@@ -306,12 +320,11 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         // ---- trees ----
         if (tid == 0) {
             uint32_t o = 0, s = 0;
-            sh_lmax = (uint32_t)build_tree(work0, kLCodes, kTables.sl_len, kTables.xl, 257, kMaxBits, lcode, llen, o, s);
+            sh_lmax = (uint32_t)build_tree(work0, kLCodes, 0, kMaxBits, lcode, llen, o, s);
             sh_optl = o; sh_statl = s;
         } else if (tid == 64) {
-            for (int i = 0; i < kDCodes; i++) five[i] = 5;
             uint32_t o = 0, s = 0;
-            sh_dmax = (uint32_t)build_tree(work1, kDCodes, five, kTables.xd, 0, kMaxBits, dcode, dlen, o, s);
+            sh_dmax = (uint32_t)build_tree(work1, kDCodes, 1, kMaxBits, dcode, dlen, o, s);
             sh_optd = o; sh_statd = s;
         }
         __syncthreads();
@@ -320,10 +333,11 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             const int lmax = (int)sh_lmax, dmax = (int)sh_dmax;
             TreeWork &w = work0;
             for (int i = 0; i < kBLCodes; i++) w.freq[i] = 0;
-            walk_lengths(llen, lmax, w.freq, nullptr, nullptr, nullptr);
-            walk_lengths(dlen, dmax, w.freq, nullptr, nullptr, nullptr);
+            BitWriter none;
+            walk_lengths<false>(llen, lmax, w.freq, none, nullptr, nullptr);
+            walk_lengths<false>(dlen, dmax, w.freq, none, nullptr, nullptr);
             uint32_t dummy = 0;
-            build_tree(w, kBLCodes, nullptr, kTables.xbl, 0, kMaxBLBits, blcode, bllen, opt_len, dummy);
+            build_tree(w, kBLCodes, 2, kMaxBLBits, blcode, bllen, opt_len, dummy);
             int max_blindex;
             for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--) if (bllen[kTables.bl_order[max_blindex]] != 0) break;
             opt_len += 3 * (uint32_t)(max_blindex + 1) + 5 + 5 + 4;
@@ -342,8 +356,8 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             } else if (btype == 2) {
                 bw.put((uint32_t)(lmax + 1 - 257), 5); bw.put((uint32_t)(dmax + 1 - 1), 5); bw.put((uint32_t)(max_blindex + 1 - 4), 4);
                 for (int r = 0; r <= max_blindex; r++) bw.put(bllen[kTables.bl_order[r]], 3);
-                walk_lengths(llen, lmax, nullptr, &bw, blcode, bllen);
-                walk_lengths(dlen, dmax, nullptr, &bw, blcode, bllen);
+                walk_lengths<true>(llen, lmax, nullptr, bw, blcode, bllen);
+                walk_lengths<true>(dlen, dmax, nullptr, bw, blcode, bllen);
             }
             sh_bitpos = bw.pos();
             bw.finish();
