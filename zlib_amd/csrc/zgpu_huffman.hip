@@ -269,6 +269,23 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *tmp, uint3
     return base + x - v;
 }
 
+#ifdef ZGPU_HUF_TIME // debug build only (scripts/huf_time.py): clock per phase, summed over chunks (lane 0's clock)
+__device__ unsigned long long huf_time[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_huf_time(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(huf_time), sizeof z);
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(huf_time), z, sizeof z);
+}
+#define HUF_T(i) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); t_acc[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#define HUF_T0() unsigned long long t_prev = wall_clock64(), t_acc[8] = {}
+#define HUF_TEND() do { if (tid == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&huf_time[i_], t_acc[i_]); } while (0)
+#else
+#define HUF_T(i) do { } while (0)
+#define HUF_T0() do { } while (0)
+#define HUF_TEND() do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
 {
     __shared__ TreeWork work0;
@@ -292,6 +309,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
     if (tid == 0) sh_bitpos = 0;
+    HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint32_t t0 = b * kBlockTokens, t1 = (b + 1 == nblocks) ? ntok : t0 + kBlockTokens, nt = t1 - t0;
@@ -317,6 +335,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         for (uint32_t i = tid; i < kLCodes; i += kThreads) work0.freq[i] = (uint16_t)hist[i];
         if (tid < kDCodes) work1.freq[tid] = (uint16_t)hist[kLCodes + tid];
         __syncthreads();
+        HUF_T(0);
         // ---- trees ----
         if (tid == 0) {
             uint32_t o = 0, s = 0;
@@ -328,6 +347,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             sh_optd = o; sh_statd = s;
         }
         __syncthreads();
+        HUF_T(1);
         if (tid == 0) {
             uint32_t opt_len = sh_optl + sh_optd, static_len = sh_statl + sh_statd;
             const int lmax = (int)sh_lmax, dmax = (int)sh_dmax;
@@ -348,6 +368,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             else if (fixed_trees || static_lenb == opt_lenb) btype = 1; // Z_FIXED: trees.c:986
             else btype = 2;
             sh_btype = btype;
+            HUF_T(2);
             // ---- block header ----
             BitWriter bw; bw.begin(out, sh_bitpos);
             bw.put((btype << 1) + eof, 3);
@@ -363,6 +384,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             bw.finish();
         }
         __syncthreads();
+        HUF_T(3);
         const uint32_t btype = sh_btype;
         uint64_t bitpos = sh_bitpos;
         if (btype == 0) {
@@ -390,6 +412,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         }
         block_start += stored_len;
         __syncthreads();
+        HUF_T(4);
         if (tid == 0) sh_bitpos = bitpos;
         __syncthreads();
     }
@@ -402,6 +425,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         meta[c].out_bytes = (uint32_t)(endpos >> 3);
         meta[c].data_type = data_type;
     }
+    HUF_TEND();
 }
 
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees)
