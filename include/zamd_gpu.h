@@ -52,6 +52,7 @@ extern "C" {
 #define ZGPU_LZ_SERIAL 1   /* one lane per chunk, tables in HBM: any level 1..9 */
 #define ZGPU_LZ_PARALLEL 2 /* static-chain search over all positions (link ring in LDS) + scan parse: levels 4..9 */
 #define ZGPU_LZ_SORTED 3   /* the same search over counting-sorted hash buckets: levels 4..9 */
+#define ZGPU_LZ_WALK 4     /* parse-driven search over the same buckets (only the positions deflate_slow searches): levels 4..9, the default */
 
 typedef struct zgpu_engine zgpu_engine;
 

@@ -24,7 +24,7 @@ bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort);
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
@@ -178,11 +178,19 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (cfg.slow && cfg.strategy == kHuffmanOnly) cfg.chain = 0;
     if (cfg.slow && cfg.strategy == kRle) cfg.chain = 1;
     int impl = p->lz_impl;
-    if (impl == ZGPU_LZ_AUTO) impl = (cfg.slow && lz_parallel_available()) ? ZGPU_LZ_SORTED : ZGPU_LZ_SERIAL;
-    if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED) && (!cfg.slow || !lz_parallel_available()))
+    // the parse-driven search plays deflate_slow's own game; the two strategies that are chain budgets of the all-position search
+    // (Z_HUFFMAN_ONLY, Z_RLE) stay with that search
+    const bool walk_ok = cfg.strategy != kHuffmanOnly && cfg.strategy != kRle;
+    if (impl == ZGPU_LZ_AUTO) {
+        static int auto_env = -1; // ZGPU_LZ_DEFAULT=3: A/B runs of the all-position search
+        if (auto_env < 0) { const char *v = getenv("ZGPU_LZ_DEFAULT"); auto_env = v ? atoi(v) : 0; }
+        impl = (cfg.slow && lz_parallel_available()) ? ((walk_ok && auto_env != ZGPU_LZ_SORTED) ? ZGPU_LZ_WALK : ZGPU_LZ_SORTED) : ZGPU_LZ_SERIAL;
+    }
+    if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
-    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_SORTED) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
+    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_WALK) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
+    if (impl == ZGPU_LZ_WALK && !walk_ok) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_WALK does not serve Z_HUFFMAN_ONLY / Z_RLE");
     if (skip0) { // a preset dictionary in front of the one chunk: the lane-per-chunk loop is the implementation that starts mid-window
         if (d_seg || in_bytes > kChunkMax || skip0 < kMinMatch || skip0 > kMaxDist || skip0 > in_bytes || (p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP | ZGPU_F_POS0 | ZGPU_F_POS0_ALL)))
             return fail(e, ZGPU_STREAM_ERROR, "dictionary chunk: 3..32506 dictionary bytes + data <= 65536, no wrapper");
@@ -221,7 +229,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    const bool check_sort = impl == ZGPU_LZ_SORTED && !e->exact_sort;
+    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, p->strategy, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
@@ -238,7 +246,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            if (impl == ZGPU_LZ_SORTED) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort);
+            if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK);
             else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {

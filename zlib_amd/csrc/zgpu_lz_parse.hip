@@ -95,8 +95,12 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_p2_time(unsign
 #define P2_T0() do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, uint32_t *__restrict__ tokens,
-                                                               ChunkMeta *meta)
+// LITE: the games have been played by walk_kernel (zgpu_lz_sorted.hip): gmv[r] holds the game of every position r a walker stood on
+// with nothing in hand and found a match at (bit r of gsv), in the format of gm[] below -- a subset of the has-positions that
+// contains the whole path, which is all that stages A2..D look at.
+template <bool LITE>
+__global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, LevelCfg cfg, const uint2 *__restrict__ recs, const uint32_t *__restrict__ gmv_all,
+                                                               const uint32_t *__restrict__ gsv_all, uint32_t *__restrict__ tokens, ChunkMeta *meta)
 {
     __shared__ __attribute__((aligned(16))) uint16_t J[kP2Win]; // successor of a has-position, window-relative (0xffff: leaves the window)
     __shared__ uint32_t HAS[kP2Words], MARK[kP2Words], COV[kP2Words], MAT[kP2Words]; // per position: has a match / on the path / inside a match
@@ -109,7 +113,8 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
     ParseCtx cx;
-    cx.rec = recs + (size_t)c * kChunkMax;
+    cx.rec = LITE ? nullptr : recs + (size_t)c * kChunkMax;
+    const uint32_t *gmv = LITE ? gmv_all + (size_t)c * kChunkMax : nullptr, *gsv = LITE ? gsv_all + (size_t)c * kP2Words : nullptr;
     cx.n = n; cx.base = chunk_base(g, c); cx.good = cfg.good; cx.lazy = cfg.lazy; cx.strategy = cfg.strategy;
     {
         // deflate.c:1278-1310 as a function of the position: the first check of "lookahead < MIN_LOOKAHEAD" happens at the first
@@ -124,8 +129,8 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
 
     P2_T0();
     // ---- 1. has(p) ----
-    for (uint32_t i = tid; i < kP2Words; i += kP2Threads) { MARK[i] = 0; COV[i] = 0; MAT[i] = 0; }
-    for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads * kP2Batch) {
+    for (uint32_t i = tid; i < kP2Words; i += kP2Threads) { MARK[i] = 0; COV[i] = 0; MAT[i] = 0; if (LITE) HAS[i] = gsv[i]; }
+    if (!LITE) for (uint32_t p0 = 0; p0 < kChunkMax; p0 += kP2Threads * kP2Batch) {
         uint2 rv[kP2Batch];
 #pragma unroll
         for (uint32_t u = 0; u < kP2Batch; u++) { const uint32_t p = p0 + u * kP2Threads + tid; rv[u] = p < n ? cx.rec[p] : make_uint2(0, 0); }
@@ -160,6 +165,25 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
             // its own: those are its neighbours' records (lanes = consecutive positions), fetched with lane shuffles; the first
             // kP2Over positions behind the wave's 64 are loaded by lanes 0..kP2Over-1 as well.  (A dependent global load per step of
             // the game -- some lane of the wave always needs one -- was 45% of this kernel.)
+            if (LITE) {
+                uint32_t gv[kP2Own];
+#pragma unroll
+                for (uint32_t i = 0; i < kP2Own; i++) {
+                    const uint32_t p = w0 + i * kP2Threads + tid;
+                    gv[i] = (p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u)) ? gmv[p] : 0;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kP2Own; i++) {
+                    const uint32_t xw = i * kP2Threads + tid, p = w0 + xw;
+                    uint32_t succ = 0xffffu;
+                    gm[i] = gv[i];
+                    if (gv[i]) {
+                        const uint32_t t = next_bit(HAS, p + (gv[i] >> 24) + ((gv[i] >> 15) & 511u), nwords);
+                        if (t < wend) succ = t - w0;
+                    }
+                    J[xw] = (uint16_t)succ;
+                }
+            } else {
 #pragma unroll
             for (uint32_t ib = 0; ib < kP2Own; ib += kP2Pair) {
                 uint2 ra[kP2Pair], rx[kP2Pair];
@@ -203,6 +227,7 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
                     }
                     J[x] = (uint16_t)succ;
                 }
+            }
             }
             __syncthreads();
             P2_T(1);
@@ -315,7 +340,8 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
                 }
                 if (lane == 0) { // the last path node of the window leads to the entry of the next one
                     uint32_t m, L, D;
-                    cx.game(last, cx.rec[last], cx.rec[last + 1], m, L, D);
+                    if (LITE) { const uint32_t gv = gmv[last]; m = last + (gv >> 24); L = (gv >> 15) & 511u; D = gv & 32767u; }
+                    else cx.game(last, cx.rec[last], cx.rec[last + 1], m, L, D);
                     sh_entry = next_bit(HAS, m + L, nwords);
                 }
             }
@@ -415,7 +441,12 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
 
 void launch_parse2(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
 {
-    hipLaunchKernelGGL(parse2_kernel, dim3(g.nchunks), dim3(kP2Threads), 0, st, g, cfg, recs, tokens, meta);
+    hipLaunchKernelGGL(parse2_kernel<false>, dim3(g.nchunks), dim3(kP2Threads), 0, st, g, cfg, recs, nullptr, nullptr, tokens, meta);
+}
+
+void launch_parse_lite(const ChunkGeom &g, LevelCfg cfg, const uint32_t *gm, const uint32_t *gs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    hipLaunchKernelGGL(parse2_kernel<true>, dim3(g.nchunks), dim3(kP2Threads), 0, st, g, cfg, nullptr, gm, gs, tokens, meta);
 }
 
 } // namespace zgpu

@@ -27,6 +27,7 @@ namespace zgpu {
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_parse_lite(const ChunkGeom &g, LevelCfg cfg, const uint32_t *gm, const uint32_t *gs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
 
 __device__ inline uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 // wave-private LDS words by byte offset (plain C++ volatile accesses through a generic pointer compile to flat_* memory instructions)
@@ -43,12 +44,13 @@ constexpr uint32_t kSuperS = 1024;   // positions per superblock of the sort pas
 constexpr uint32_t kSPad = 8;        // entries in front of every chunk's S (group loads may reach below index 0)
 constexpr uint32_t kSStride = kChunkMax + kSPad;
 
-// workspace layout: 256-byte header (fault word) | S (u16) | rank, then idx, by position (u16) | bucket-head bits | records
+// workspace layout: 256-byte header (fault word) | S (u16) | rank, then idx, by position (u16) | bucket-head bits | records |
+// ir: idx | rank << 16 by position (u32; what walk_kernel looks a position up with)
 
 constexpr uint32_t kHeadWords = kChunkMax / 32;                  // dwords of bucket-head bits per chunk ...
 constexpr uint32_t kHeadStride = kHeadWords + kChunkMax / 64 / 2; // ... followed by one u16 per 64 S indices (dwords per chunk)
 
-size_t lz_sorted_workspace_bytes(uint32_t batch) { return 256 + (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kHeadStride * 4 + kChunkMax * 8) + 1024; }
+size_t lz_sorted_workspace_bytes(uint32_t batch) { return 256 + (size_t)batch * (kSStride * 2 + kChunkMax * 2 + kHeadStride * 4 + kChunkMax * 8 + kChunkMax * 4) + 1024; }
 
 // For block w of 64 S indices (1024 lanes, lane w holds the 64 head bits of its block): the distance from index 64*w down
 // to the last bucket head below the block, 65535 if there is none (w == 0) or it is farther.  The rank of an S entry in
@@ -87,7 +89,8 @@ __global__ void __launch_bounds__(1024) heads_below_kernel(uint32_t *__restrict_
 #endif
 constexpr uint32_t kSortWaves = ZGPU_SORT_WAVES, kSortThreads = 64 * kSortWaves; // waves per chunk: 4 or 8 (or 16)
 
-__global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all)
+__global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all,
+                                                            uint32_t *__restrict__ ir_all)
 {
     __shared__ uint16_t cnt[kHashSize];                                         // counts, then bucket starts
     __shared__ __attribute__((aligned(16))) uint32_t in_stage[kSuperS / 4 + 4]; // 1 KiB of input + 8 bytes of the next
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
-    uint32_t *hd = heads_all + (size_t)c * kHeadStride;
+    uint32_t *hd = heads_all + (size_t)c * kHeadStride, *ir = ir_all + (size_t)c * kChunkMax;
     if (tid < kSPad) S[-(int)kSPad + (int)tid] = 0;
     for (uint32_t i = tid; i < kChunkMax / 32; i += kSortThreads) hd[i] = 0; // (pass C sets bits; the barriers of pass A lie in between)
     for (uint32_t i = tid; i < kHashSize / 2; i += kSortThreads) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
@@ -199,6 +202,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
             if (p < npos) {
                 const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]), r = rk[p], id = (uint32_t)cnt[h] + r;
                 S[id] = (uint16_t)p;
+                ir[p] = id | (r << 16);
                 if (r == 0) atomicOr(&hd[id >> 5], 1u << (id & 31u)); // bucket head
             }
         }
@@ -229,7 +233,7 @@ struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 __device__ inline uint32_t lds_add_rtn32_nowait(uint32_t a, uint32_t v) { uint32_t o; asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(v) : "memory"); return o; }
 
 __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all,
-                                                           uint32_t *__restrict__ fault)
+                                                           uint32_t *__restrict__ fault, uint32_t *__restrict__ ir_all)
 {
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kHashSize / 2]; // count of hash h in half (h & 1) of word h >> 1; later the bucket starts
     __shared__ uint32_t wave_tot[kS3Waves];
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     chunk_span(g, c, lo, n);
     const uint8_t *src = g.in + lo;
     uint16_t *S = S_all + (size_t)c * kSStride + kSPad, *rk = rank_all + (size_t)c * kChunkMax;
-    uint32_t *hd = heads_all + (size_t)c * kHeadStride;
+    uint32_t *hd = heads_all + (size_t)c * kHeadStride, *ir = ir_all + (size_t)c * kChunkMax;
     if (threadIdx.x < kSPad) S[-(int)kSPad + (int)threadIdx.x] = 0; // the pad reads as "position 0" (match3's finished lanes)
     uint32_t last_of_half0 = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
@@ -334,6 +338,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
             if (p < npos) {
                 const uint32_t id = (uint32_t)start[hash_of(bv[u])] + rv[u];
                 rk[p] = (uint16_t)id;
+                ir[p] = id | (rv[u] << 16);
                 if (rv[u] == 0) atomicOr(&heads[id >> 5], 1u << (id & 31u));
             }
         }
@@ -391,14 +396,14 @@ __device__ inline void lds_ld2bytes(uint32_t a, uint32_t &b0, uint32_t &b1)
 struct __attribute__((packed, aligned(2))) U64u { uint64_t v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950 (scripts/micro/global_unaligned.hip)
 constexpr uint32_t kM2Threads = 1024;
 
-// chunk bytes -> LDS (zero padded to kChunkMax + 64), by all kM2Threads lanes of the workgroup
-__device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32, uint32_t tid)
+// chunk bytes -> LDS (zero padded to kChunkMax + 64), by all T lanes of the workgroup
+template <uint32_t T> __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32, uint32_t tid)
 {
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const uint4 *s128 = reinterpret_cast<const uint4 *>(src);
         uint4 *d128 = reinterpret_cast<uint4 *>(d32);
         const uint32_t nv = n >> 4;
-        for (uint32_t i = tid; i < (kChunkMax + 64) / 16; i += kM2Threads) {
+        for (uint32_t i = tid; i < (kChunkMax + 64) / 16; i += T) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (i < nv) v = s128[i];
             else if (i == nv) {
@@ -409,7 +414,7 @@ __device__ inline void stage_chunk(const uint8_t *src, uint32_t n, uint32_t *d32
             d128[i] = v;
         }
     } else {
-        for (uint32_t i = tid; i < (kChunkMax + 64) / 4; i += kM2Threads) {
+        for (uint32_t i = tid; i < (kChunkMax + 64) / 4; i += T) {
             uint32_t v = 0;
             for (uint32_t k = 0; k < 4; k++) { uint32_t a = (i << 2) + k; if (a < n) v |= (uint32_t)src[a] << (8 * (k & 3)); }
             d32[i] = v;
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     uint2 *rec = recs + (size_t)c * kChunkMax;
     const uint32_t npos = n >= 3 ? n - 2 : 0;
     const uint32_t base = chunk_base(g, c);
-    stage_chunk(src, n, d32, tid);
+    stage_chunk<kM2Threads>(src, n, d32, tid);
     if (tid == 0) *work_next = 0;
     for (uint32_t q2 = npos + tid; q2 < n; q2 += kM2Threads) rec[q2] = make_uint2((uint32_t)src[q2] << 24, 0); // the last two positions carry no hash
     __syncthreads();
@@ -623,8 +628,240 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
     }
 }
 
+// ------------------------------------------------------------------------------------------------- K2w
+// Parse-driven search (levels 4-9; replaces match3_kernel + the game stage of parse2_kernel).  match3 searches every
+// position with the full chain budget because the parse that decides which searches matter runs after it; deflate_slow
+// itself (deflate.c:1554-1674) calls longest_match at a quarter of the positions, often with a quarter of the budget, and
+// walks a sixth of the candidates (tests/tools/walk_model.c).  Here the parse drives the search:
+//
+//   * The chunk is cut into blocks of 64 positions; a WALKER (one lane) takes a block and runs the reference's loop from the
+//     block's first position in the neutral state (nothing in hand, prev_length = MIN_MATCH-1), calling for searches as the
+//     loop does: at a neutral position with the full budget, at the position behind a match shorter than max_lazy with the
+//     match as the seed (and a quarter of the budget from good_match on).
+//   * Whatever happens from a neutral position depends on that position alone, so a walker that arrives, neutral, at a
+//     position another walker has been at in the same state stops there (one bit per position in LDS, claimed with an atomic
+//     OR): every neutral position is worked on once, and parses started 64 positions apart fall into step after a match or
+//     two (0.8 neutral positions on average, tests/tools/walk_model.c).  The walkers' paths form a forest in which the path
+//     from position 0 -- the reference's parse -- is complete.  A walker whose path has merged takes the next block.
+//   * A lane searches like a lane of match3 (same step: two-byte quick check at the best length, candidates that pass are
+//     parked on the wave's stack, 64 parked candidates are compared at full occupancy and folded into their owners' keys),
+//     but the lanes of a wave are at different points of different searches.  They advance in bodies of four candidates; a
+//     lane whose search is over waits until the wave's next PASS (when 16 lanes wait, or none is searching), which plays
+//     the parse for all of them, claims positions, hands out blocks and starts the next searches.  Everything a start needs
+//     from memory (index and rank of the position: one dword of `ir`) is fetched at least one pass ahead, for the position
+//     behind the current one and for the position behind the match in hand.
+//   * Output: for every neutral position r that a game started from, gm[r] = (m - r) << 24 | len << 15 | dist of the match the
+//     game ends with, and bit r of the chunk's bitmap gs: what parse2_kernel's stage A1 derives from match3's records,
+//     restricted to the positions some walker stood on (which include the whole path).  parse2 (lite form) does the rest.
+constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = 64, kWTrig = 16;
+constexpr uint32_t kWNeuBytes = kChunkMax / 8;
+constexpr uint32_t kWLds = kM3DataLds + 16 + kWNeuBytes + kWWaves * kM3WaveLds;
+static_assert(2 * kWLds <= 160 * 1024, "two walker workgroups per CU");
+enum : uint32_t { W_NEED = 0, W_LIMBO = 1, W_READY = 2, W_SEARCH = 3, W_DONE = 4 };
+#ifdef ZGPU_WALK_STATS // debug build only: 0 bodies, 1 active lane-steps, 2 passes, 3 lanes served by passes, 4 searches, 5 folds, 6 parked, 7 limbo starts
+__device__ unsigned long long walk_stats[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_stats(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(walk_stats), sizeof z);
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(walk_stats), z, sizeof z);
+}
+#define W_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&walk_stats[i], v_); } while (0)
+#else
+#define W_STAT(i, v) do { } while (0)
+#endif
+__device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
+
+__global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
+                                                            uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *d32 = lds;
+    uint32_t *ctrl = lds + kM3DataLds / 4; // [0]: next block to hand out
+    uint32_t *NEU = ctrl + 4;              // bit p: some walker stands, or stood, at p with nothing in hand
+    const uint8_t *d8 = reinterpret_cast<const uint8_t *>(d32);
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ring = (uint32_t)__builtin_amdgcn_readfirstlane(lds_off(lds) + kM3DataLds + 16 + kWNeuBytes + wave * kM3WaveLds), slot = ring + kRing * 4, pw = slot + 64 * 4;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
+    const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
+    uint32_t *gm = gm_all + (size_t)c * kChunkMax, *gs = gs_all + (size_t)c * (kChunkMax / 32);
+    const uint32_t npos = n >= 3 ? n - 2 : 0, base = chunk_base(g, c);
+    stage_chunk<kWThreads>(src, n, d32, tid);
+    for (uint32_t i = tid; i < kChunkMax / 32; i += kWThreads) { NEU[i] = 0; gs[i] = 0; }
+    if (tid == 0) ctrl[0] = 0;
+    __syncthreads();
+    int slide_at; // visited positions >= slide_at see the slid window (ParseCtx::slide_at, zgpu_lz_parse.hip)
+    {
+        const int room = (int)(2 * kWSize - base), b0 = (int)n < room ? (int)n : room;
+        const int a = b0 - (int)kMinLookahead + 1, b = (int)(kWSize + kMaxDist) - (int)base;
+        slide_at = a > b ? a : b;
+    }
+    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = (n + kWBlk - 1) / kWBlk;
+    const uint32_t lanebits = lane << 16, dummy = ring + (kRing - 1) * 4;
+    // walker
+    uint32_t st = W_NEED, x = 0, handL = kMinMatch - 1, handM = 0, handD = 0, gstart = 0;
+    uint32_t irx = 0, irn = 0, irE = 0, irl = 0; // idx | rank << 16 of: x, x + 1, the position behind the match in hand, a position asked for in the last pass
+    bool haveE = false;
+    // search (as in match3_kernel); keys: len >= nice: 1<<31 | q<<9 | len, else len<<16 | q -- nearest candidate first = largest q
+    uint32_t rem = 0, best = kMinMatch - 1, key_seen = 0, sentinel = 0, scan2 = 0, boff = dbase + 1;
+    int thr = 0, thr_next = 0, gq = -(int)kSPad; // gq: S index of the group of four candidates that is on its way (cqn)
+    uint64_t cq = 0, cqn = 0;
+    unsigned long long amask = 0, jmask = 0; // lanes walking a chain; lanes that join them when their first group has arrived
+    uint32_t tail = 0;
+
+    auto fold = [&]() {
+        const uint32_t cnt = tail < 64 ? tail : 64;
+        W_STAT(5, 1); W_STAT(6, cnt);
+        tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail - cnt);
+        if (lane < cnt) {
+            const uint32_t e = lds_ld32(ring + ((tail + lane) << 2));
+            const uint32_t q = e & 0xffffu, o = (e >> 16) & 63u;
+            const uint32_t po = lds_ld16(pw + o * 2), look = n - po, cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
+            uint32_t l = 0, xx;
+            for (;;) {
+                xx = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + po + l);
+                if (xx != 0 || l + 4 >= cap) break;
+                l += 4;
+            }
+            uint32_t len = xx ? l + ((uint32_t)__builtin_ctz(xx) >> 3) : l + 4;
+            len = len < cap ? len : cap;
+            if (len >= kMinMatch) lds_max32(slot + o * 4, len >= nice ? (0x80000000u | (q << 9) | len) : ((len << 16) | q));
+        }
+        const uint32_t key = lds_ld32(slot + lane * 4);
+        if (key != key_seen) {
+            key_seen = key;
+            best = (key >> 31) ? key & 0x1ffu : key >> 16;
+            boff = dbase + best - 1;
+            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 8);
+        }
+        amask &= ~mask_lt_i32((int)key, 0); // nice_match: that walk is over (deflate.c:1224)
+    };
+    auto gload = [&]() -> uint64_t { const int gi = gq < -(int)kSPad ? -(int)kSPad : gq; return reinterpret_cast<const U64u *>(S + gi)->v; };
+
+    for (;;) {
+        // ================================================= pass: the parse for every lane whose search is over =================================================
+        while (tail) fold();
+        const bool fin = st == W_SEARCH && !(((amask | jmask) >> lane) & 1ull);
+        W_STAT(2, 1); W_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(fin || st == W_LIMBO || st == W_NEED)));
+        if (st == W_LIMBO) { irx = irl; st = W_READY; } // what the last pass asked for has arrived
+        uint32_t y = 0, irY = 0;
+        bool toN = false, haveIr = false;
+        if (fin) {
+            uint32_t len = kMinMatch - 1, dist = 0;
+            if (key_seen != sentinel) {
+                const bool nz = key_seen >> 31;
+                len = nz ? key_seen & 0x1ffu : key_seen >> 16;
+                dist = x - (nz ? (key_seen >> 9) & 0xffffu : key_seen & 0xffffu);
+            }
+            if (len <= 5 && (cfg.strategy == kFiltered || (len == kMinMatch && dist > kTooFar))) len = kMinMatch - 1; // deflate.c:1601-1611
+            bool emit = false;
+            if (len > handL) { // a (longer) match at x: the byte before it, if a match was in hand, becomes a literal (deflate.c:1642-1651)
+                if (handL < kMinMatch) gstart = x;
+                handL = len; handD = dist; handM = x;
+                if (len < cfg.lazy && x + 1 < npos) { x = x + 1; irx = irn; st = W_READY; } // look one position further (deflate.c:1588)
+                else emit = true;
+                haveE = false; // (the position behind the match in hand has moved)
+            } else if (handL >= kMinMatch) emit = true;            // the match in hand stands (deflate.c:1611-1634)
+            else { y = x + 1; irY = irn; toN = haveIr = true; }    // a literal
+            if (emit) {
+                gm[gstart] = ((handM - gstart) << 24) | (handL << 15) | handD;
+                atomicOr(&gs[gstart >> 5], 1u << (gstart & 31u));
+                y = handM + handL; irY = irE; haveIr = haveE; toN = true;
+                handL = kMinMatch - 1;
+            }
+        }
+        if (toN) { // neutral at y
+            st = W_NEED;
+            if (y < n) {
+                const uint32_t bit = 1u << (y & 31u);
+                if (!(atomicOr(&NEU[y >> 5], bit) & bit)) { // nobody has been here: go on
+                    x = y;
+                    if (haveIr) { irx = irY; st = W_READY; }
+                    else { irl = y < npos ? ir[y] : 0; st = W_LIMBO; W_STAT(7, 1); }
+                }
+            }
+        }
+        {   // blocks for the walkers that have none
+            const unsigned long long nm = __builtin_amdgcn_ballot_w64(st == W_NEED);
+            if (nm) {
+                const int first = __builtin_ctzll(nm);
+                uint32_t b0 = 0;
+                if ((int)lane == first) b0 = atomicAdd(&ctrl[0], (uint32_t)__popcll(nm));
+                b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, first);
+                if (st == W_NEED) {
+                    const uint32_t b = b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
+                    if (b >= nblk) st = W_DONE;
+                    else {
+                        const uint32_t y2 = b * kWBlk, bit = 1u << (y2 & 31u);
+                        if (!(atomicOr(&NEU[y2 >> 5], bit) & bit)) { x = y2; handL = kMinMatch - 1; irl = y2 < npos ? ir[y2] : 0; st = W_LIMBO; }
+                        // (else: a walker from further down passed through here; the next pass asks for another block)
+                    }
+                }
+            }
+        }
+        bool fresh = false;
+        if (st == W_READY) { // start the search at x with the match in hand (length handL, 2: none) as the seed
+            const uint32_t seed = handL, idx = irx & 0xffffu, rank = irx >> 16, budget = seed >= cfg.good ? chainQ : chainF;
+            uint32_t avail = x < npos ? (rank < budget ? rank : budget) : 0;
+            irn = x + 1 < npos ? ir[x + 1] : 0;
+            if (seed >= kMinMatch) { const uint32_t E = handM + handL; irE = E < npos ? ir[E] : 0; haveE = true; }
+            const int w = (int)(x + base);
+            thr = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;              // first candidate: dist <= MAX_DIST, not NIL (deflate.c:1588)
+            thr_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base;  // later ones: strictly inside (deflate.c:1163)
+            // the one position whose first candidate can sit at window index 32768: NIL after the slide (deflate.c:1309-1312)
+            if (x + base == kWSize + kMaxDist && avail != 0 && (int)x >= slide_at && (uint32_t)S[idx - 1] + base == kWSize) avail = 0;
+            best = seed; sentinel = (seed << 16) | 0xffffu; key_seen = sentinel; boff = dbase + best - 1;
+            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 8);
+            lds_st32(slot + lane * 4, sentinel);
+            lds_st16(pw + lane * 2, x);
+            rem = avail + 4; // (the end of the body in which the first group arrives takes 4 off)
+            gq = (int)idx - 4;
+            st = W_SEARCH;
+            fresh = avail != 0;
+            W_STAT(4, 1);
+        }
+        jmask = __builtin_amdgcn_ballot_w64(fresh);
+        cqn = gload(); // every lane: the group it waits for (again), or the first group of its new search
+        if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) break;
+        const unsigned long long smask = __builtin_amdgcn_ballot_w64(st == W_SEARCH);
+        const uint32_t idle = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(st == W_LIMBO || st == W_NEED));
+
+        // ================================================= bodies of four candidates until enough lanes wait =================================================
+        for (;;) {
+            if (amask) {
+                W_STAT(0, 1);
+                const unsigned long long amask0 = amask;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t q = (uint32_t)(cq >> (48 - 16 * j)) & 0xffffu;
+                    uint32_t b0, b1;
+                    lds_ld2bytes(boff + q, b0, b1);
+                    W_STAT(1, __popcll(amask));
+                    amask &= mask_le_i32(thr, (int)q); // beyond MAX_DIST (or the NIL position): the chain ends here
+                    if (j == 0) thr = (int)sel_mask(amask0, (uint32_t)thr_next, (uint32_t)thr);
+                    const unsigned long long m = amask & mask_eq_u32(b0 | (b1 << 8), scan2);
+                    if (m) {
+                        stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, q | lanebits);
+                        tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
+                        if (tail >= 64) fold();
+                    }
+                    amask &= mask_gt_u32(rem, j + 1);
+                }
+            }
+            cq = cqn; gq -= 4; cqn = gload();
+            rem = rem > 4 ? rem - 4 : 0;
+            amask |= jmask; jmask = 0;
+            if (amask == 0 || (uint32_t)__popcll(smask & ~amask) + idle >= kWTrig) break;
+        }
+    }
+}
+
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort)
+// `walk`: parse-driven search (walk_kernel + the lite parse) instead of the all-position search (match3_kernel + parse2_kernel)
+void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk)
 {
     uint8_t *w = static_cast<uint8_t *>(workspace);
     const size_t nch = g.nchunks;
@@ -633,22 +870,34 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
     uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
     uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * kHeadStride);
+    uint32_t *ir = reinterpret_cast<uint32_t *>(recs + nch * kChunkMax);
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
     static int sort_env = -1;
     if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
     if (exact_sort || sort_env == 1) {
-        hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads);
+        hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
         hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
     }
     else {
-        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault);
+        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir);
         static int fault_test = -1; // tests/test_gpu_deflate.py: exercise the engine's fallback without a real fault
         if (fault_test < 0) fault_test = getenv("ZGPU_SORT_FAULT_TEST") ? 1 : 0;
         if (fault_test) hipMemsetAsync(fault, 1, 4, st);
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
+    if (walk) { // the records' memory holds the walkers' output: gm (u32 per position), then the bitmaps gs (2048 words per chunk)
+        uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
+        static bool opt_inw = false;
+        if (!opt_inw) { hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds); opt_inw = true; }
+        hipLaunchKernelGGL(walk_kernel, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs);
+        prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+        prof_span_begin(prof, st, &ev);
+        launch_parse_lite(g, cfg, gm, gs, tokens, meta, st);
+        prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
+        return;
+    }
     static bool opt_in3 = false;
     if (!opt_in3) { hipFuncSetAttribute(reinterpret_cast<const void *>(match3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kM3Lds); opt_in3 = true; }
     hipLaunchKernelGGL(match3_kernel, dim3(g.nchunks), dim3(kM2Threads), kM3Lds, st, g, cfg, S, heads, recs);
