@@ -393,7 +393,8 @@ __device__ inline void lds_ld2bytes(uint32_t a, uint32_t &b0, uint32_t &b1)
 {
     asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(a) : "memory");
 }
-struct __attribute__((packed, aligned(2))) U64u { uint64_t v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950 (scripts/micro/global_unaligned.hip)
+struct __attribute__((packed, aligned(2))) U64u { uint64_t v; };
+struct __attribute__((packed, aligned(2))) U128u { uint4 v; }; // 8 bytes at 2-byte alignment: one global_load_dwordx2 on gfx950 (scripts/micro/global_unaligned.hip)
 constexpr uint32_t kM2Threads = 1024;
 
 // chunk bytes -> LDS (zero padded to kChunkMax + 64), by all T lanes of the workgroup
@@ -707,8 +708,11 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
     bool haveE = false;
     // search (as in match3_kernel); keys: len >= nice: 1<<31 | q<<9 | len, else len<<16 | q -- nearest candidate first = largest q
     uint32_t rem = 0, best = kMinMatch - 1, key_seen = 0, sentinel = 0, scan2 = 0, boff = dbase + 1;
-    int thr = 0, thr_next = 0, gq = -(int)kSPad; // gq: S index of the group of four candidates that is on its way (cqn)
-    uint64_t cq = 0, cqn = 0;
+    // candidates arrive in groups of eight (16 bytes of S), three groups per lane under way: cq is being examined, cqn and cqnn
+    // are in flight (a lane's loads are scattered over S: nothing is shared between lanes, every group comes from L2 or beyond, and
+    // two bodies is what that takes); cqf/cqf2 receive the first two groups of the searches a pass starts
+    int thr = 0, thr_next = 0, gq = -(int)kSPad, gqf = -(int)kSPad; // gq: S index of the group in cqnn
+    uint4 cq = make_uint4(0, 0, 0, 0), cqn = cq, cqnn = cq, cqf = cq, cqf2 = cq;
     unsigned long long amask = 0, jmask = 0; // lanes walking a chain; lanes that join them when their first group has arrived
     uint32_t tail = 0;
 
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
         }
         amask &= ~mask_lt_i32((int)key, 0); // nice_match: that walk is over (deflate.c:1224)
     };
-    auto gload = [&]() -> uint64_t { const int gi = gq < -(int)kSPad ? -(int)kSPad : gq; return reinterpret_cast<const U64u *>(S + gi)->v; };
+    auto gload = [&](int gi) -> uint4 { gi = gi < -(int)kSPad ? -(int)kSPad : gi; return reinterpret_cast<const U128u *>(S + gi)->v; };
 
     for (;;) {
         // ================================================= pass: the parse for every lane whose search is over =================================================
@@ -817,26 +821,28 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 8);
             lds_st32(slot + lane * 4, sentinel);
             lds_st16(pw + lane * 2, x);
-            rem = avail + 4; // (the end of the body in which the first group arrives takes 4 off)
-            gq = (int)idx - 4;
+            rem = avail + 8; // (the end of the body in which the first group arrives takes 8 off)
+            gqf = (int)idx - 8;
             st = W_SEARCH;
             fresh = avail != 0;
             W_STAT(4, 1);
         }
         jmask = __builtin_amdgcn_ballot_w64(fresh);
-        cqn = gload(); // every lane: the group it waits for (again), or the first group of its new search
+        if (!fresh) gqf = -(int)kSPad;
+        cqf = gload(gqf); cqf2 = gload(gqf - 8); // every lane (the ones that start nothing load the pad)
         if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) break;
         const unsigned long long smask = __builtin_amdgcn_ballot_w64(st == W_SEARCH);
         const uint32_t idle = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(st == W_LIMBO || st == W_NEED));
 
-        // ================================================= bodies of four candidates until enough lanes wait =================================================
-        for (;;) {
+        // ================================================= bodies of eight candidates until enough lanes wait =================================================
+        for (bool first = true;; first = false) {
             if (amask) {
                 W_STAT(0, 1);
                 const unsigned long long amask0 = amask;
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t q = (uint32_t)(cq >> (48 - 16 * j)) & 0xffffu;
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t wd = j < 2 ? cq.w : j < 4 ? cq.z : j < 6 ? cq.y : cq.x; // nearest candidate = highest address
+                    const uint32_t q = (j & 1) ? wd & 0xffffu : wd >> 16;
                     uint32_t b0, b1;
                     lds_ld2bytes(boff + q, b0, b1);
                     W_STAT(1, __popcll(amask));
@@ -851,8 +857,14 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                     amask &= mask_gt_u32(rem, j + 1);
                 }
             }
-            cq = cqn; gq -= 4; cqn = gload();
-            rem = rem > 4 ? rem - 4 : 0;
+            cq = cqn; cqn = cqnn; gq -= 8;
+            if (first && jmask) { // the searches the pass started: their first two groups
+                cq.x = sel_mask(jmask, cqf.x, cq.x); cq.y = sel_mask(jmask, cqf.y, cq.y); cq.z = sel_mask(jmask, cqf.z, cq.z); cq.w = sel_mask(jmask, cqf.w, cq.w);
+                cqn.x = sel_mask(jmask, cqf2.x, cqn.x); cqn.y = sel_mask(jmask, cqf2.y, cqn.y); cqn.z = sel_mask(jmask, cqf2.z, cqn.z); cqn.w = sel_mask(jmask, cqf2.w, cqn.w);
+                gq = (int)sel_mask(jmask, (uint32_t)(gqf - 16), (uint32_t)gq);
+            }
+            cqnn = gload(gq);
+            rem = rem > 8 ? rem - 8 : 0;
             amask |= jmask; jmask = 0;
             if (amask == 0 || (uint32_t)__popcll(smask & ~amask) + idle >= kWTrig) break;
         }
