@@ -389,6 +389,18 @@ __device__ inline uint32_t lds_ld32u(uint32_t a) // 4 bytes at any LDS byte offs
     asm volatile("ds_read2_b32 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(al) : "memory");
     return __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, a & 3);
 }
+// xa, xb = the first and the second four bytes of (8 bytes at LDS offset a) ^ (8 bytes at LDS offset b), any alignment: three aligned
+// dwords of each string in flight together, one wait
+__device__ inline void lds_cmp8(uint32_t a, uint32_t b, uint32_t &xa, uint32_t &xb)
+{
+    uint64_t va, vb; uint32_t va2, vb2;
+    const uint32_t aa = a & ~3u, ba = b & ~3u;
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read_b32 %1, %4 offset:8\n\tds_read2_b32 %2, %5 offset1:1\n\tds_read_b32 %3, %5 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(va), "=&v"(va2), "=&v"(vb), "=&v"(vb2) : "v"(aa), "v"(ba) : "memory");
+    const uint32_t a0 = __builtin_amdgcn_alignbyte((uint32_t)(va >> 32), (uint32_t)va, a & 3), a1 = __builtin_amdgcn_alignbyte(va2, (uint32_t)(va >> 32), a & 3);
+    const uint32_t b0 = __builtin_amdgcn_alignbyte((uint32_t)(vb >> 32), (uint32_t)vb, b & 3), b1 = __builtin_amdgcn_alignbyte(vb2, (uint32_t)(vb >> 32), b & 3);
+    xa = a0 ^ b0; xb = a1 ^ b1;
+}
 __device__ inline void lds_ld2bytes(uint32_t a, uint32_t &b0, uint32_t &b1)
 {
     asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b0), "=&v"(b1) : "v"(a) : "memory");
@@ -654,7 +666,10 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 //   * Output: for every neutral position r that a game started from, gm[r] = (m - r) << 24 | len << 15 | dist of the match the
 //     game ends with, and bit r of the chunk's bitmap gs: what parse2_kernel's stage A1 derives from match3's records,
 //     restricted to the positions some walker stood on (which include the whole path).  parse2 (lite form) does the rest.
-constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = 64, kWTrig = 16;
+#ifndef ZGPU_WTRIG
+#define ZGPU_WTRIG 16 // lanes waiting for a pass that make the wave run one
+#endif
+constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = 64, kWTrig = ZGPU_WTRIG;
 constexpr uint32_t kWNeuBytes = kChunkMax / 8;
 constexpr uint32_t kWLds = kM3DataLds + 16 + kWNeuBytes + kWWaves * kM3WaveLds;
 static_assert(2 * kWLds <= 160 * 1024, "two walker workgroups per CU");
@@ -670,6 +685,22 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_stats(uns
 #define W_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&walk_stats[i], v_); } while (0)
 #else
 #define W_STAT(i, v) do { } while (0)
+#endif
+#ifdef ZGPU_WALK_TIME // debug build only (scripts/walk_time.py): clock cycles of a wave in 0 passes (rest), 1 bodies (without 2), 2 folds inside bodies, 3 setup, 4 drain folds, 5 parse + claims, 6 blocks
+__device__ unsigned long long walk_time[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_time(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(walk_time), sizeof z);
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(walk_time), z, sizeof z);
+}
+#define W_T0() unsigned long long wt_prev = __builtin_readcyclecounter(), wt_fold = 0
+#define W_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&walk_time[i], t_ - wt_prev - ((i) == 1 ? wt_fold : 0)); if ((i) == 1 && lane == 0) atomicAdd(&walk_time[2], wt_fold); wt_fold = 0; wt_prev = t_; } while (0)
+#define W_TF(stmt) do { const unsigned long long f0_ = __builtin_readcyclecounter(); stmt; wt_fold += __builtin_readcyclecounter() - f0_; } while (0)
+#else
+#define W_T0() do { } while (0)
+#define W_T(i) do { } while (0)
+#define W_TF(stmt) stmt
 #endif
 __device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
 
@@ -708,11 +739,15 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
     bool haveE = false;
     // search (as in match3_kernel); keys: len >= nice: 1<<31 | q<<9 | len, else len<<16 | q -- nearest candidate first = largest q
     uint32_t rem = 0, best = kMinMatch - 1, key_seen = 0, sentinel = 0, scan2 = 0, boff = dbase + 1;
-    // candidates arrive in groups of eight (16 bytes of S), three groups per lane under way: cq is being examined, cqn and cqnn
-    // are in flight (a lane's loads are scattered over S: nothing is shared between lanes, every group comes from L2 or beyond, and
-    // two bodies is what that takes); cqf/cqf2 receive the first two groups of the searches a pass starts
-    int thr = 0, thr_next = 0, gq = -(int)kSPad, gqf = -(int)kSPad; // gq: S index of the group in cqnn
-    uint4 cq = make_uint4(0, 0, 0, 0), cqn = cq, cqnn = cq, cqf = cq, cqf2 = cq;
+    // candidates arrive in groups of eight (16 bytes of S).  A lane's loads are scattered over S: nothing is shared between lanes and
+    // every group comes from L2 or beyond, a latency of several bodies; streaming the groups one body ahead (as match3 does with
+    // its coalesced loads) left every body waiting for memory.  So a pass fetches the first 32 candidates of the searches it
+    // starts at once (F0..F3; most chains are no longer), the lanes take them over one body later (G0..G3, consumed by rotation),
+    // and a chain that goes on after 32 candidates is refilled by the next pass.
+    int thr = 0, thr_next = 0, gi = -(int)kSPad; // gi: S index of the next group to fetch
+    uint4 G0 = make_uint4(0, 0, 0, 0), G1 = G0, G2 = G0, G3 = G0, F0 = G0, F1 = G0, F2 = G0, F3 = G0;
+    uint32_t left = 0;  // groups in G0..G3
+    bool cont = false;  // out of candidates in registers, chain not finished
     unsigned long long amask = 0, jmask = 0; // lanes walking a chain; lanes that join them when their first group has arrived
     uint32_t tail = 0;
 
@@ -724,13 +759,13 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             const uint32_t e = lds_ld32(ring + ((tail + lane) << 2));
             const uint32_t q = e & 0xffffu, o = (e >> 16) & 63u;
             const uint32_t po = lds_ld16(pw + o * 2), look = n - po, cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
-            uint32_t l = 0, xx;
-            for (;;) {
-                xx = lds_ld32u(dbase + q + l) ^ lds_ld32u(dbase + po + l);
-                if (xx != 0 || l + 4 >= cap) break;
-                l += 4;
+            uint32_t l = 0, xa, xb;
+            for (;;) { // eight bytes of both strings per round trip
+                lds_cmp8(dbase + q + l, dbase + po + l, xa, xb);
+                if ((xa | xb) != 0 || l + 8 >= cap) break;
+                l += 8;
             }
-            uint32_t len = xx ? l + ((uint32_t)__builtin_ctz(xx) >> 3) : l + 4;
+            uint32_t len = xa ? l + ((uint32_t)__builtin_ctz(xa) >> 3) : xb ? l + 4 + ((uint32_t)__builtin_ctz(xb) >> 3) : l + 8;
             len = len < cap ? len : cap;
             if (len >= kMinMatch) lds_max32(slot + o * 4, len >= nice ? (0x80000000u | (q << 9) | len) : ((len << 16) | q));
         }
@@ -739,16 +774,20 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             key_seen = key;
             best = (key >> 31) ? key & 0x1ffu : key >> 16;
             boff = dbase + best - 1;
-            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 8);
+            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 16);
         }
         amask &= ~mask_lt_i32((int)key, 0); // nice_match: that walk is over (deflate.c:1224)
     };
     auto gload = [&](int gi) -> uint4 { gi = gi < -(int)kSPad ? -(int)kSPad : gi; return reinterpret_cast<const U128u *>(S + gi)->v; };
 
+    W_T0();
+    W_T(3);
     for (;;) {
         // ================================================= pass: the parse for every lane whose search is over =================================================
         while (tail) fold();
-        const bool fin = st == W_SEARCH && !(((amask | jmask) >> lane) & 1ull);
+        W_T(4);
+        if (cont && (key_seen >> 31)) cont = false; // (the drain found a nice_match: no refill)
+        const bool fin = st == W_SEARCH && !(((amask | jmask) >> lane) & 1ull) && !cont;
         W_STAT(2, 1); W_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(fin || st == W_LIMBO || st == W_NEED)));
         if (st == W_LIMBO) { irx = irl; st = W_READY; } // what the last pass asked for has arrived
         uint32_t y = 0, irY = 0;
@@ -788,6 +827,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                 }
             }
         }
+        W_T(5);
         {   // blocks for the walkers that have none
             const unsigned long long nm = __builtin_amdgcn_ballot_w64(st == W_NEED);
             if (nm) {
@@ -806,6 +846,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                 }
             }
         }
+        W_T(6);
         bool fresh = false;
         if (st == W_READY) { // start the search at x with the match in hand (length handL, 2: none) as the seed
             const uint32_t seed = handL, idx = irx & 0xffffu, rank = irx >> 16, budget = seed >= cfg.good ? chainQ : chainF;
@@ -818,56 +859,86 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             // the one position whose first candidate can sit at window index 32768: NIL after the slide (deflate.c:1309-1312)
             if (x + base == kWSize + kMaxDist && avail != 0 && (int)x >= slide_at && (uint32_t)S[idx - 1] + base == kWSize) avail = 0;
             best = seed; sentinel = (seed << 16) | 0xffffu; key_seen = sentinel; boff = dbase + best - 1;
-            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 8);
+            scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 16);
             lds_st32(slot + lane * 4, sentinel);
             lds_st16(pw + lane * 2, x);
-            rem = avail + 8; // (the end of the body in which the first group arrives takes 8 off)
-            gqf = (int)idx - 8;
+            rem = avail;
+            gi = (int)idx - 8;
             st = W_SEARCH;
             fresh = avail != 0;
             W_STAT(4, 1);
         }
+        if (cont) { cont = false; fresh = true; } // refill
         jmask = __builtin_amdgcn_ballot_w64(fresh);
-        if (!fresh) gqf = -(int)kSPad;
-        cqf = gload(gqf); cqf2 = gload(gqf - 8); // every lane (the ones that start nothing load the pad)
+        {
+            const int ga = fresh ? gi : -(int)kSPad; // every lane loads (the ones that start nothing: the pad)
+            F0 = gload(ga); F1 = gload(ga - 8); F2 = gload(ga - 16); F3 = gload(ga - 24);
+            if (fresh) gi -= 32;
+        }
+        W_T(0);
         if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) break;
         const unsigned long long smask = __builtin_amdgcn_ballot_w64(st == W_SEARCH);
         const uint32_t idle = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(st == W_LIMBO || st == W_NEED));
 
         // ================================================= bodies of eight candidates until enough lanes wait =================================================
         for (bool first = true;; first = false) {
+            const unsigned long long amask0 = amask; // the lanes that examine a group in this body
             if (amask) {
                 W_STAT(0, 1);
-                const unsigned long long amask0 = amask;
+                // the quick-check bytes of all eight candidates in one round trip, read at the best length the body starts with: a fold
+                // inside the body moves best/boff/scan2 for the next body, the rest of this one goes on with what it read (walking with a
+                // stale best length is exact, see match3_kernel)
+                const uint32_t scan0 = scan2;
+                uint32_t qv[8], bb[8];
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t wd = j < 2 ? cq.w : j < 4 ? cq.z : j < 6 ? cq.y : cq.x; // nearest candidate = highest address
-                    const uint32_t q = (j & 1) ? wd & 0xffffu : wd >> 16;
-                    uint32_t b0, b1;
-                    lds_ld2bytes(boff + q, b0, b1);
+                    const uint32_t wd = j < 2 ? G0.w : j < 4 ? G0.z : j < 6 ? G0.y : G0.x; // nearest candidate = highest address
+                    qv[j] = (j & 1) ? wd & 0xffffu : wd >> 16;
+                }
+                {
+                    uint32_t a0 = boff + qv[0], a1 = boff + qv[1], a2 = boff + qv[2], a3 = boff + qv[3], a4 = boff + qv[4], a5 = boff + qv[5], a6 = boff + qv[6], a7 = boff + qv[7];
+                    uint32_t hi[8]; // (d16 loads would fill both halves of one register, but with SRAM ECC on they clear the other half)
+                    asm volatile("ds_read_u8 %0, %16\n\tds_read_u8 %8, %16 offset:1\n\tds_read_u8 %1, %17\n\tds_read_u8 %9, %17 offset:1\n\t"
+                                 "ds_read_u8 %2, %18\n\tds_read_u8 %10, %18 offset:1\n\tds_read_u8 %3, %19\n\tds_read_u8 %11, %19 offset:1\n\t"
+                                 "ds_read_u8 %4, %20\n\tds_read_u8 %12, %20 offset:1\n\tds_read_u8 %5, %21\n\tds_read_u8 %13, %21 offset:1\n\t"
+                                 "ds_read_u8 %6, %22\n\tds_read_u8 %14, %22 offset:1\n\tds_read_u8 %7, %23\n\tds_read_u8 %15, %23 offset:1\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]), "=&v"(bb[4]), "=&v"(bb[5]), "=&v"(bb[6]), "=&v"(bb[7]),
+                                   "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
+                                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "memory");
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) bb[j] |= hi[j] << 16;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t q = qv[j];
                     W_STAT(1, __popcll(amask));
                     amask &= mask_le_i32(thr, (int)q); // beyond MAX_DIST (or the NIL position): the chain ends here
                     if (j == 0) thr = (int)sel_mask(amask0, (uint32_t)thr_next, (uint32_t)thr);
-                    const unsigned long long m = amask & mask_eq_u32(b0 | (b1 << 8), scan2);
+                    const unsigned long long m = amask & mask_eq_u32(bb[j], scan0);
                     if (m) {
                         stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, q | lanebits);
                         tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
-                        if (tail >= 64) fold();
+                        if (tail >= 64) W_TF(fold());
                     }
                     amask &= mask_gt_u32(rem, j + 1);
                 }
             }
-            cq = cqn; cqn = cqnn; gq -= 8;
-            if (first && jmask) { // the searches the pass started: their first two groups
-                cq.x = sel_mask(jmask, cqf.x, cq.x); cq.y = sel_mask(jmask, cqf.y, cq.y); cq.z = sel_mask(jmask, cqf.z, cq.z); cq.w = sel_mask(jmask, cqf.w, cq.w);
-                cqn.x = sel_mask(jmask, cqf2.x, cqn.x); cqn.y = sel_mask(jmask, cqf2.y, cqn.y); cqn.z = sel_mask(jmask, cqf2.z, cqn.z); cqn.w = sel_mask(jmask, cqf2.w, cqn.w);
-                gq = (int)sel_mask(jmask, (uint32_t)(gqf - 16), (uint32_t)gq);
+            G0 = G1; G1 = G2; G2 = G3;
+            left = left ? left - 1 : 0;
+            if (first && jmask) { // the searches the pass started or refilled: their 32 candidates have had a body's time to arrive
+                if ((jmask >> lane) & 1ull) { G0 = F0; G1 = F1; G2 = F2; G3 = F3; left = 4; }
             }
-            cqnn = gload(gq);
-            rem = rem > 8 ? rem - 8 : 0;
+            rem = sel_mask(amask0, rem > 8 ? rem - 8 : 0, rem);
+            {   // lanes that walk on but have nothing left in registers wait for the next pass
+                const unsigned long long cm = amask & mask_eq_u32(left, 0u);
+                cont = cont || ((cm >> lane) & 1ull);
+                amask &= ~cm;
+            }
             amask |= jmask; jmask = 0;
             if (amask == 0 || (uint32_t)__popcll(smask & ~amask) + idle >= kWTrig) break;
         }
+        W_T(1);
     }
 }
 
