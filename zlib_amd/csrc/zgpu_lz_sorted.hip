@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 //     game ends with, and bit r of the chunk's bitmap gs: what parse2_kernel's stage A1 derives from match3's records,
 //     restricted to the positions some walker stood on (which include the whole path).  parse2 (lite form) does the rest.
 #ifndef ZGPU_WTRIG
-#define ZGPU_WTRIG 16 // lanes waiting for a pass that make the wave run one
+#define ZGPU_WTRIG 48 // lanes waiting for a pass that make the wave run one
 #endif
 constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = 64, kWTrig = ZGPU_WTRIG;
 constexpr uint32_t kWNeuBytes = kChunkMax / 8;
@@ -870,10 +870,13 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
         }
         if (cont) { cont = false; fresh = true; } // refill
         jmask = __builtin_amdgcn_ballot_w64(fresh);
-        {
-            const int ga = fresh ? gi : -(int)kSPad; // every lane loads (the ones that start nothing: the pad)
-            F0 = gload(ga); F1 = gload(ga - 8); F2 = gload(ga - 16); F3 = gload(ga - 24);
-            if (fresh) gi -= 32;
+        if (fresh) { // only the lanes that start or refill load, and only the groups the chain has (a scattered 16-byte load is 64 requests to the
+                     // address unit whatever the lanes ask for; F0..F3 are read back by these lanes alone)
+            F0 = gload(gi);
+            if (rem > 8) F1 = gload(gi - 8);
+            if (rem > 16) F2 = gload(gi - 16);
+            if (rem > 24) F3 = gload(gi - 24);
+            gi -= 32;
         }
         W_T(0);
         if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) break;
