@@ -39,7 +39,18 @@ def parse():
     ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip inflate / level 1 / level 9 / host-buffer runs")
     return ap.parse_args()
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(sample, level, threads, op="deflate"):
@@ -153,17 +164,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    eng.profile(True)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile(False)
+    def timed(fn, steps, warmup):
+        """warmup untimed calls, then exactly `steps` calls between barrier + synchronize; returns (seconds, per-stage device time)"""
+        for _ in range(warmup):
+            fn()
+        eng.profile(True)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile(False)
+        return dt, prof
+
+    dt, prof = timed(step, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,42 +190,37 @@ def main():
         if not ok:
             sys.exit("inflate output differs from the original input")
 
+    def roofline_of(prof, steps, in_bytes, out_bytes, op, level):
+        """Roofline object for the dominant stage of a run: algorithmic bytes (input read + stream written) per launch over the
+        stage's HIP-event time per launch (events recorded by the engine on its launch stream)."""
+        stages = {k: v for k, v in prof.items() if v[1] > 0}
+        if not stages:
+            return None
+        dom = max(stages, key=lambda k: stages[k][0])
+        ms, launches = stages[dom]
+        per_launch_bytes = (in_bytes + out_bytes) * steps / launches
+        achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel cannot be counted from inside this process (rocprofv3 collects FETCH_SIZE and WRITE_SIZE in
+        # separate passes, scripts/prof_cache.sh); the committed counters are quoted when they are for this very workload and kernel.
+        traffic, traffic_src, limiter = None, None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            key = "%s-L%d-%s-%.0fgib-%s" % (op, level, a.workload, in_bytes / 2**30, dom)
+            if key in tj and (op != "deflate" or a.lz == "auto"):
+                traffic, traffic_src, limiter = tj[key]["traffic_bytes_per_launch"], tj[key]["source"], tj[key].get("limiter")
+        except (OSError, ValueError, KeyError):
+            pass
+        return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": int(per_launch_bytes), "limiter": limiter,
+                "avg_launch_ms": round(ms / launches, 4), "launches": launches,
+                "stage_ms_per_step": {k: round(v[0] / steps, 3) for k, v in stages.items()}}
+
     if rank == 0:
         res = state["res"]
         ratio = nbytes / res.out_bytes
         total_in = nbytes * world * a.steps
         value = total_in / dt / 2**30
-        # dominant stage by device time
-        stages = {k: v for k, v in prof.items() if v[1] > 0}
-        dom = max(stages, key=lambda k: stages[k][0]) if stages else None
-        roof = None
-        if dom:
-            ms, launches = stages[dom]
-            per_launch_bytes = (nbytes + res.out_bytes) * a.steps / launches  # algorithmic: input read + stream written
-            achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
-            # HBM traffic of the dominant kernel cannot be counted from inside this process (rocprofv3 collects FETCH_SIZE and
-            # WRITE_SIZE in separate passes, scripts/prof_round.sh); the committed counters are quoted when they are for
-            # this very workload and kernel, otherwise the field stays null.
-            traffic, traffic_src = None, None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")))
-                if (a.op == "deflate" and dom == "match" and a.level == 6 and a.workload == "silesia-mix" and abs(nbytes / 2**30 - 4.0) < 1e-9
-                        and a.lz in ("auto", "sorted")):
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_final_traffic.json"
-                if a.op == "inflate" and dom == "inflate" and a.level == 6 and a.workload == "silesia-mix" and abs(nbytes / 2**30 - 4.0) < 1e-9:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_inflate_traffic.json")))
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_inflate_traffic.json"
-            except (OSError, ValueError, KeyError):
-                pass
-            limiter = {"match": "VALU issue (78-84 % of the vector-ALU peak, rocprofv3 PMC in profiles/); not HBM",
-                       "inflate": "latency of the per-token chains of one reader and one writer wave per segment, four segments per CU "
-                                  "(32 KiB LDS ring each); vector and scalar pipes 25-28 % busy (profiles/r01_inflate_4gib_L6_summary.txt); not HBM"}.get(dom)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                    "limiter": limiter,
-                    "avg_launch_ms": round(ms / launches, 4), "launches": launches,
-                    "stage_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in stages.items()}}
         line = {
             "metric": "GiB/s raw input %s (deflate level %d)" % ("decompressed" if a.op == "inflate" else "compressed", a.level),
             "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -219,13 +230,77 @@ def main():
                 a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
                 "gathered_bytes": int(state.get("gathered", res.out_bytes))},
-            "roofline": roof,
+            "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),
         }
+    # ---- the other configurations of BASELINE.json on the same input, outside the timed region of the headline (N = 1 only):
+    #      inflate of the headline's stream (config 4), level 1 and level 9 (config 3), and the host-buffer entry point (PCIe included)
+    if world == 1 and a.op == "deflate" and not a.no_extras:
+        extra = {}
+        z_len = state["res"].out_bytes
+
+        def one_level(level, steps):
+            st = {}
+
+            def f():
+                st["res"] = eng.deflate_device(src.data_ptr(), nbytes, level, dst2.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
+                                               lz_impl=gpu.LZ_AUTO, stream=stream)
+            d, pr = timed(f, steps, 1)
+            return {"metric": "GiB/s raw input compressed (deflate level %d)" % level, "value": round(nbytes * steps / d / 2**30, 4),
+                    "unit": "GiB/s", "steps": steps, "warmup": 1, "ms_per_step": round(d / steps * 1e3, 3),
+                    "compression_ratio": round(nbytes / st["res"].out_bytes, 4),
+                    "roofline": roofline_of(pr, steps, nbytes, st["res"].out_bytes, "deflate", level)}
+
+        # config 4: the stream the headline produced, back to the original bytes (checked)
+        src2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+        def inf():
+            state["ires"] = eng.inflate_device(dst.data_ptr(), z_len, offs.data_ptr(), nchunks, src2.data_ptr(), nbytes, stream=stream)
+        d, pr = timed(inf, a.steps, 1)
+        if not bool(torch.equal(src, src2)):
+            sys.exit("inflate output differs from the original input")
+        extra["inflate"] = {"metric": "GiB/s raw output decompressed (inflate of the level-%d stream)" % a.level,
+                            "value": round(nbytes * a.steps / d / 2**30, 4), "unit": "GiB/s", "steps": a.steps, "warmup": 1,
+                            "ms_per_step": round(d / a.steps * 1e3, 3), "bytes_equal": True,
+                            "roofline": roofline_of(pr, a.steps, nbytes, z_len, "inflate", a.level)}
+        del src2
+        dst2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+        extra["level1"] = one_level(1, a.steps)
+        extra["level9"] = one_level(9, max(1, a.steps // 2))  # (the deepest chains: fewer steps, stated in "steps")
+        del dst2
+        # the zlib-API path hands over host buffers: H2D of the input, the same kernels, D2H of the stream (SURVEY.md 8d "end-to-end")
+        import ctypes as C
+        import numpy as np
+        host_n = min(nbytes, 1 << 30)
+        host_in = src[:host_n].cpu().numpy()
+        host_cap = eng.L.zgpu_deflate_bound(host_n, 65536)
+        host_out = np.zeros(host_cap, dtype=np.uint8)  # (touched: the timed call does not pay for page faults of a fresh allocation)
+        hp = gpu._Params(a.level, 65536, gpu.F_FINAL | gpu.F_ZLIB_WRAP, gpu.LZ_AUTO, 0, 0)
+        hres = gpu.DeflateResult()
+        best = None
+        for _ in range(2):  # the second call finds the engine's staging buffers allocated
+            t0 = time.perf_counter()
+            rc = eng.L.zgpu_deflate_host(eng.h, host_in.ctypes.data, host_n, C.byref(hp), host_out.ctypes.data, host_cap, None, C.byref(hres))
+            d = time.perf_counter() - t0
+            if rc != 0:
+                sys.exit("zgpu_deflate_host failed: %d" % rc)
+            best = d if best is None or d < best else best
+        extra["end_to_end_host_buffers"] = {"metric": "GiB/s raw input compressed, host buffers in and out (H2D, kernels, D2H; pageable memory)",
+                                            "value": round(host_n / best / 2**30, 4), "unit": "GiB/s", "input_bytes": host_n,
+                                            "stream_bytes": int(hres.out_bytes), "note": "zgpu_deflate_host, best of two calls"}
+        line["extra"] = extra
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             sample_bytes = min(nbytes, a.cpu_sample_mib << 20)
             sample = src[:sample_bytes].cpu().numpy().tobytes()
-            threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(sample, a.level, threads, a.op)
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+            cb = cpu_baseline(sample, a.level, threads, a.op)
+            one = cpu_baseline(sample[: min(len(sample), 48 << 20)], a.level, 1, a.op)
+            cb["single_thread"] = {"value": one["value"], "unit": "GiB/s", "sample": one["sample"]}
+            cb["cpu_model"] = cpu_model()
+            line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

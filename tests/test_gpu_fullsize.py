@@ -1,4 +1,4 @@
-"""BASELINE.json configs 2-4 at their full size (4 GiB of the seeded Silesia-mix, generated in HBM): the engine's
+"""BASELINE.json configs 2-5 at their full size (4 GiB of the seeded Silesia-mix, generated in HBM): the engine's
 chunk segments are checked against the reference's golden hashes for all 4096 sampled chunk ids, the stream inflates
 back to the input on the device, and the Adler-32 trailer matches a checksum of checksums computed independently."""
 import hashlib
@@ -26,7 +26,7 @@ def test_4gib_level6_against_reference_hashes_and_roundtrip():
     cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
     dst = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
-    for level, col in ((6, 4), (1, 2)):
+    for level, col in ((6, 4), (1, 2), (9, 6)):
         res = eng.deflate_device(src.data_ptr(), nbytes, level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP, d_offsets=offs.data_ptr())
         assert res.nchunks == nchunks
         o = offs.cpu().numpy()
@@ -48,3 +48,73 @@ def test_4gib_level6_against_reference_hashes_and_roundtrip():
         assert torch.equal(src, back)
         del back
     eng.close()
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_8gib_logtext_rank_share_against_reference_hashes(rank):
+    """Config 5's per-GPU share: 131072 chunks (8 GiB) of the 64 GiB log-text, as rank `rank` of 8 compresses them (raw body, BFINAL
+    only on the last rank), every sampled chunk of the range against the reference's hashes, Adler-32 and round trip on the device."""
+    import torch
+    import zlib_amd
+    from zlib_amd import gpu, shard
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_logtext.json")))
+    world = 8
+    lo, hi = shard.chunk_range(g["total_chunks"], rank, world)
+    nchunks = hi - lo
+    assert nchunks == 131072
+    nbytes = nchunks * 65536
+    eng = zlib_amd.Engine(0)
+    dev = torch.device("cuda", 0)
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    eng.corpus_fill_device(g["kind"], g["seed"], lo, nchunks, src.data_ptr())
+    cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
+    dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+    res = eng.deflate_device(src.data_ptr(), nbytes, 6, dst.data_ptr(), cap, flags=gpu.F_FINAL if rank == world - 1 else 0, d_offsets=offs.data_ptr())
+    assert res.nchunks == nchunks
+    o = offs.cpu().numpy()
+    assert o[0] == 0 and o[-1] == res.out_bytes
+    rows = [r for r in g["rows"] if lo <= r[0] < hi]
+    assert len(rows) >= 32
+    for row in rows:
+        k = row[0] - lo
+        if row[0] == g["total_chunks"] - 1:
+            continue  # (carries BFINAL here, the flush marker in the fixture)
+        seg = dst[int(o[k]): int(o[k + 1])].cpu().numpy().tobytes()
+        assert [len(seg), hashlib.sha256(seg).hexdigest()[:16]] == row[4:6], (rank, row[0])
+    assert res.adler32 == eng.adler32_device(src.data_ptr(), nbytes)
+    if rank == world - 1:  # a complete raw stream of its own: decodes back on the device
+        back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        r = eng.inflate_device(dst.data_ptr(), res.out_bytes, offs.data_ptr(), nchunks, back.data_ptr(), nbytes)
+        assert r.out_bytes == nbytes and r.adler32 == res.adler32
+        assert torch.equal(src, back)
+    eng.close()
+
+
+def test_rccl_gather_world1_on_device_tensors():
+    """The N > 1 framing path of bench.py with the nccl (= RCCL) backend, world size 1: communicator set-up, the all_gather of
+    (size, Adler-32, length) and the framing run on device tensors; the stream must equal the one-call stream of the engine."""
+    import torch
+    import torch.distributed as dist
+    import zlib_amd
+    from zlib_amd import gpu, shard
+    from oracle import corpus_py as CP
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", world_size=1, rank=0, device_id=dev)
+    try:
+        eng = zlib_amd.Engine(0)
+        n = 96
+        data = CP.chunks(CP.KIND_LOGTEXT, 5, n)
+        src = torch.from_numpy(data.copy()).to(dev)
+        cap = eng.L.zgpu_deflate_bound(src.numel(), 65536)
+        body = torch.empty(cap, dtype=torch.uint8, device=dev)
+        res = eng.deflate_device(src.data_ptr(), src.numel(), 6, body.data_ptr(), cap, flags=gpu.F_FINAL)
+        stream, total = shard.gather_stream(body[: res.out_bytes], res.adler32, src.numel(), 6)
+        whole = torch.empty(cap, dtype=torch.uint8, device=dev)
+        res2 = eng.deflate_device(src.data_ptr(), src.numel(), 6, whole.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP)
+        assert total == res2.out_bytes and torch.equal(stream, whole[: res2.out_bytes])
+        eng.close()
+    finally:
+        dist.destroy_process_group()

@@ -28,7 +28,10 @@
 
 namespace zgpu {
 
-constexpr uint32_t kP2Threads = 1024, kP2Win = 8192, kP2Own = kP2Win / kP2Threads, kP2Blk = kP2Win / 64;
+#ifndef ZGPU_P2WIN
+#define ZGPU_P2WIN 8192 // positions per window of the path threading
+#endif
+constexpr uint32_t kP2Threads = 1024, kP2Win = ZGPU_P2WIN, kP2Own = kP2Win / kP2Threads, kP2Blk = kP2Win / 64;
 constexpr uint32_t kP2Words = kChunkMax / 32, kP2Batch = 8, kP2Pair = 4, kP2Over = 8; // positions per lane whose loads are in flight together; overhang of a wave's games
 constexpr uint32_t kNone = 0xffffffffu;
 
@@ -170,7 +173,12 @@ __global__ void __launch_bounds__(kP2Threads, 8) parse2_kernel(ChunkGeom g, Leve
 #pragma unroll
                 for (uint32_t i = 0; i < kP2Own; i++) {
                     const uint32_t p = w0 + i * kP2Threads + tid;
-                    gv[i] = (p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u)) ? gmv[p] : 0;
+                    gv[i] = p < n ? gmv[p] : 0; // (all positions, whatever the words of the others hold: loads under a per-lane condition are waited for one by one)
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kP2Own; i++) {
+                    const uint32_t p = w0 + i * kP2Threads + tid;
+                    if (!(p < n && ((HAS[p >> 5] >> (p & 31u)) & 1u))) gv[i] = 0;
                 }
 #pragma unroll
                 for (uint32_t i = 0; i < kP2Own; i++) {

@@ -669,7 +669,10 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 #ifndef ZGPU_WTRIG
 #define ZGPU_WTRIG 48 // lanes waiting for a pass that make the wave run one
 #endif
-constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = 64, kWTrig = ZGPU_WTRIG;
+#ifndef ZGPU_WBLK
+#define ZGPU_WBLK 64 // positions per block
+#endif
+constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = ZGPU_WBLK, kWTrig = ZGPU_WTRIG;
 constexpr uint32_t kWNeuBytes = kChunkMax / 8;
 constexpr uint32_t kWLds = kM3DataLds + 16 + kWNeuBytes + kWWaves * kM3WaveLds;
 static_assert(2 * kWLds <= 160 * 1024, "two walker workgroups per CU");
