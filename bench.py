@@ -53,6 +53,23 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cores():
+    """(threads worth starting, logical CPUs of the host): the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a GPU box hands a one-GPU job about 16 cores of a much larger host; more threads than that only take turns)"""
+    try:
+        host = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host = os.cpu_count() or 1
+    n = host
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64), host
+
+
 def cpu_baseline(sample, level, threads, op="deflate"):
     """Time the reference (oracle/_ref) -- or the CPU restatement -- per 64 KiB chunk on `threads` host threads.
     op "inflate": the chunks are compressed first (untimed) and the timed part is the reference's inflate of those streams."""
@@ -292,11 +309,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             sample_bytes = min(nbytes, a.cpu_sample_mib << 20)
             sample = src[:sample_bytes].cpu().numpy().tobytes()
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                threads = os.cpu_count() or 1
+            threads, host_cpus = usable_cores()
             cb = cpu_baseline(sample, a.level, threads, a.op)
+            cb["host_logical_cpus"] = host_cpus
             one = cpu_baseline(sample[: min(len(sample), 48 << 20)], a.level, 1, a.op)
             cb["single_thread"] = {"value": one["value"], "unit": "GiB/s", "sample": one["sample"]}
             cb["cpu_model"] = cpu_model()

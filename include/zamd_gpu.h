@@ -84,6 +84,10 @@ typedef struct {
     uint32_t error_msg;   /* index into zgpu_inflate_message() */
     uint32_t crc32;       /* CRC-32 of the produced bytes */
     uint32_t reserved;
+    /* zgpu_inflate_stream_host2 with ZGPU_INF_STREAM (otherwise in_used = in_bytes, the flags 0): */
+    uint64_t in_used;     /* input bytes consumed: up to the end of the final block, or of the last segment that decoded */
+    uint32_t stream_end;  /* the final block was reached */
+    uint32_t incomplete;  /* the input stops inside a block: out_bytes / in_used cover the segments in front of it (possibly none) */
 } zgpu_inflate_result;
 
 /* ---- engine lifetime ---- */
@@ -92,6 +96,11 @@ int zgpu_engine_create(int device, zgpu_engine **out);
 void zgpu_engine_destroy(zgpu_engine *e);
 const char *zgpu_engine_error(const zgpu_engine *e);
 const char *zgpu_version(void);
+
+/* deflateTune (qcsrc/deflate.c:453-470): while `on`, the deflate calls of this engine use these four parameters of the match
+ * search instead of the level's row of configuration_table (deflate.c:137-149); the level keeps its compress function
+ * (deflate_fast for 1..3, deflate_slow for 4..9). */
+int zgpu_deflate_set_tuning(zgpu_engine *e, int on, uint32_t good_length, uint32_t max_lazy, uint32_t nice_length, uint32_t max_chain);
 
 /* worst-case output bytes for in_bytes of input cut into chunk_size pieces (framing included) */
 uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size);
@@ -153,6 +162,15 @@ int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_by
  * that does not split into independent segments (any other producer's stream) is decoded as ZGPU_WHOLE_STREAM. */
 int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap,
                              zgpu_inflate_result *res);
+/* The same for the REST OF A STREAM (flags = ZGPU_INF_STREAM): `in` starts at a block boundary and may reach beyond the end of the
+ * deflate data -- trailers, further members, anything.  The stream ends with its final block (res->stream_end, res->in_used =
+ * offset of the first byte behind it); input that stops inside a block is not an error: the call delivers the full-flush
+ * segments in front of the incomplete one (res->incomplete, res->in_used, res->out_bytes; all three can be 0) and is repeated from
+ * in + in_used when more has arrived.  This is what inflate() of the zlib API needs (qcsrc/inflate.c:1114: DONE leaves the rest of
+ * the input with the caller).  flags = 0 is zgpu_inflate_stream_host. */
+#define ZGPU_INF_STREAM 1u
+int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap,
+                              zgpu_inflate_result *res);
 const char *zgpu_inflate_message(uint32_t index);
 /* Preset dictionary of the inflate calls that follow (inflateSetDictionary, qcsrc/inflate.c:1200-1236): the first segment of a
  * call may reach back into its last min(len, 32768) bytes.  Stays set until replaced; len 0 clears it. */

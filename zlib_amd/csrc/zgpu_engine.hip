@@ -27,7 +27,8 @@ size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
-                uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
+                uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
+                const uint64_t *h_offsets = nullptr);
 
 } // namespace zgpu
 
@@ -45,6 +46,7 @@ struct zgpu_engine {
     uint16_t *tables = nullptr;  // serial LZ only
     uint32_t tables_cap = 0;
     void *par_ws = nullptr;      // parallel LZ only
+    int tuned = 0; uint32_t tune[4] = {0, 0, 0, 0}; // zgpu_deflate_set_tuning: good, lazy, nice, chain instead of the level's
     int exact_sort = 0;          // sticky: the fast sort's self-check failed once on this engine (zgpu_lz_sorted.hip, pass V)
     uint32_t par_cap = 0;
     uint64_t *offsets = nullptr; // nchunks+1 segment offsets of the current call
@@ -173,6 +175,11 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (p->strategy < 0 || p->strategy > (int)kFixed) return fail(e, ZGPU_STREAM_ERROR, "strategy must be 0..4");
     LevelCfg cfg = level_cfg(p->level);
     cfg.strategy = (uint32_t)p->strategy;
+    if (e->tuned) { // deflateTune (deflate.c:453-470): the level keeps its function, the four parameters are the caller's
+        // (a budget of 0 never runs out in the reference: its loop counts down past zero, deflate.c:1163 -- no chain of a chunk is longer than 65535)
+        cfg.good = e->tune[0]; cfg.lazy = e->tune[1]; cfg.nice = e->tune[2]; cfg.chain = (e->tune[3] && e->tune[3] < 0xffffu) ? e->tune[3] : 0xffffu;
+        if (cfg.nice > kMaxMatch) cfg.nice = kMaxMatch; // (no match is longer: the same searches)
+    }
     // the chain budget of the all-position search says it all for two strategies (deflate.c:1594-1599): no candidate at all,
     // or the nearest one only (and then only at distance 1, see match3_kernel)
     if (cfg.slow && cfg.strategy == kHuffmanOnly) cfg.chain = 0;
@@ -363,6 +370,13 @@ uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size)
     if (chunk_size == 0 || chunk_size > kChunkMax) chunk_size = kChunkMax;
     uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1;
     return in_bytes + nchunks * 40 + 16; // <= 6 block headers of 5 bytes + 5-byte marker per chunk, + zlib framing
+}
+
+int zgpu_deflate_set_tuning(zgpu_engine *e, int on, uint32_t good_length, uint32_t max_lazy, uint32_t nice_length, uint32_t max_chain)
+{
+    if (!e) return ZGPU_STREAM_ERROR;
+    e->tuned = on != 0; e->tune[0] = good_length; e->tune[1] = max_lazy; e->tune[2] = nice_length; e->tune[3] = max_chain;
+    return ZGPU_OK;
 }
 
 int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, void *d_out, uint64_t out_cap,

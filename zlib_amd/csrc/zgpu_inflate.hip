@@ -34,15 +34,15 @@ void launch_stitch(const uint8_t *slots, const ChunkMeta *meta, const uint64_t *
 
 enum InfMsg : uint32_t {
     kMsgNone = 0, kMsgBlockType, kMsgStoredLen, kMsgTooMany, kMsgCodeLens, kMsgRepeat, kMsgLitLens, kMsgDists, kMsgLitCode, kMsgDistCode,
-    kMsgTooFar, kMsgTruncated, kMsgOutput, kMsgTrailing, kMsgShort, kMsgCount
+    kMsgTooFar, kMsgTruncated, kMsgOutput, kMsgTrailing, kMsgShort, kMsgTable, kMsgCount
 };
 static const char *const kInfMessages[kMsgCount] = {
     "", "invalid block type", "invalid stored block lengths", "too many length or distance symbols", "invalid code lengths set",
     "invalid bit length repeat", "invalid literal/lengths set", "invalid distances set", "invalid literal/length code", "invalid distance code",
     "invalid distance too far back", "segment ends inside a block", "segment decodes to more than chunk_size bytes",
-    "segment holds data after its last block", "segment decodes to fewer than chunk_size bytes"};
+    "segment holds data after its last block", "segment decodes to fewer than chunk_size bytes", "segment table out of range"};
 
-struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t pad; };
+struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t used; }; // used: input bytes up to the end of the last block | final block seen << 31
 
 constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 256;
 constexpr uint32_t kOutRing = 32768, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
@@ -57,12 +57,13 @@ struct InflateLds {
     uint32_t dtab[1 << kDBits];
     uint32_t stage[kStageDwords]; // ring of input dwords
     uint32_t tok[128];            // token ring, reader -> writer, handed over in halves of 64
-    uint32_t abort_flag, pad0;    // writer -> reader: stop, the output is void
+    uint32_t abort_flag, end_bits; // writer -> reader: stop, the output is void; reader -> writer: bits of the segment used when it ended
     uint16_t lens[320];
     uint16_t lsym[288], dsym[32]; // symbols sorted by (length, symbol) for the long-code walk
     uint16_t lcount[16], dcount[16];
     uint16_t work_offs[16], work_first[16], work_start[16];
     uint32_t build_rc, build_n;
+    uint32_t end_final, pad1;     // reader -> writer: the segment ended with a final block
 };
 static_assert(sizeof(InflateLds) <= 40448, "four waves per CU");
 
@@ -278,14 +279,19 @@ __device__ inline void block_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0
 __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
                                                       uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
                                                       uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
-                                                      const uint8_t *__restrict__ dict, uint32_t dict_len)
+                                                      const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t stream_mode)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
     const uint32_t c = blockIdx.x, lane = threadIdx.x & 63u;
     const uint32_t role = uni(threadIdx.x >> 6); // 0 reader, 1 writer
     if (c >= nchunks) return;
-    const uint64_t gc = chunk0 + c, seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
+    const uint64_t gc = chunk0 + c;
+    uint64_t seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
+    // the table may arrive next to the data from anywhere: an entry that does not lie inside the input, runs backwards or is longer than
+    // a 32-bit bit count can express is an error of that segment, decoded as an empty one (nothing outside the input is ever read)
+    const bool bad_table = seg_lo > seg_hi || seg_hi > in_bytes || seg_hi - seg_lo >= (1ull << 29);
+    if (bad_table) { seg_lo = 0; seg_hi = 0; }
     const bool must_be_final = gc == last_chunk;
     // chunk_size_arg == 0: "compact" mode, segments of any size up to 64 KiB are decoded into per-chunk slots and
     // concatenated afterwards (used for streams whose chunks are not all full, e.g. flushed mid-chunk)
@@ -298,12 +304,12 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
     // a preset dictionary (inflateSetDictionary, inflate.c:1200-1236) is what the window holds before the first byte: in the ring it
     // sits right below position 0, and the first segment may reach that much farther back
     const uint32_t reach = (gc == 0) ? dict_len : 0u;
-    if (threadIdx.x == 0) L.abort_flag = 0;
+    if (threadIdx.x == 0) { L.abort_flag = 0; L.end_bits = 0; L.end_final = 0; }
     INF_T0();
 
     if (role == 0) {
         // =========================================== reader ===========================================
-        uint32_t err = kMsgNone;
+        uint32_t err = bad_table ? (uint32_t)kMsgTable : (uint32_t)kMsgNone;
         uint32_t wr = 0;   // tokens put into the ring so far
         bool stop = false; // the writer gave up (its error comes first in stream order)
         auto publish = [&]() { // the current half is complete: hand it over, the other half is free from here on
@@ -566,8 +572,10 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
             const uint32_t used = consumed_bits(b);
             if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
             else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
+            else if (stream_mode && seen_final) { }                           // stream mode: the stream ends where its final block ends, whatever follows
             else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
             else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
+            if (!err && lane == 0) { L.end_bits = used; L.end_final = seen_final ? 1u : 0u; }
         }
 #ifdef ZGPU_INF_DEBUG2
         if (err && lane == 0) printf("chunk %u reader err %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
@@ -713,6 +721,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
     if (lane == 0) {
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
+        status[c].used = err ? 0u : (((L.end_bits + 7u) >> 3) | (L.end_final << 31));
 #ifdef ZGPU_INF_TIME
         t_acc[6] = n_mat;
         for (int i_ = 0; i_ < 16; i_++) if (t_acc[i_]) atomicAdd(&inf_time[i_], t_acc[i_]);
@@ -722,26 +731,54 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
 }
 
 // first failing chunk + total bytes (one workgroup; chunk order matters for "first")
-__global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *st, uint32_t nchunks, uint64_t chunk0, uint32_t chunk_size, uint64_t *acc)
+// stream_mode: the segments are candidate pieces of ONE stream that ends where its first final block ends.  Segments behind that
+// one are not part of it (whatever they decoded to is dropped: their meta.out_bytes is cleared for the scan and the stitcher);
+// and when the only failure is the last segment stopping inside a block, the segments before it stand as a partial result.
+__global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *st, uint32_t nchunks, uint64_t chunk0, uint32_t chunk_size, uint64_t *acc,
+                                                              uint32_t stream_mode, uint64_t last_chunk, ChunkMeta *meta, uint32_t trunc_msg)
 {
-    // acc[0] total bytes, acc[1] first bad chunk (+1, 0 = none), acc[2] its code, acc[3] its msg, acc[4] "short chunk before the end" flag
-    __shared__ unsigned long long bad_min;
+    // acc[0] total bytes, acc[1] first bad chunk (+1, 0 = none), acc[2] its code, acc[3] its msg, acc[4] "short chunk before the end" flag,
+    // acc[5] chunk that ends the stream (+1), acc[6] input bytes of that chunk used, acc[7] chunk at which a partial result stops (+1)
+    __shared__ unsigned long long bad_min, fin_min;
     __shared__ unsigned long long total;
-    if (threadIdx.x == 0) { bad_min = ~0ull; total = 0; }
+    if (threadIdx.x == 0) { bad_min = ~0ull; fin_min = ~0ull; total = 0; }
     __syncthreads();
-    unsigned long long t = 0, bad = ~0ull;
-    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) { t += st[i].out_bytes; if (st[i].code != 0 && bad == ~0ull) bad = chunk0 + i; }
-    atomicAdd(&total, t);
+    if (acc[5] != 0 || acc[7] != 0) { // an earlier batch ended the stream (or the partial result): nothing of this batch counts
+        if (meta) for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) meta[i].out_bytes = 0;
+        return;
+    }
+    unsigned long long bad = ~0ull, fin = ~0ull;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) {
+        if (st[i].code != 0 && bad == ~0ull) bad = chunk0 + i;
+        if (stream_mode && st[i].code == 0 && (st[i].used >> 31) && fin == ~0ull) fin = chunk0 + i;
+    }
     atomicMin(&bad_min, bad);
+    atomicMin(&fin_min, fin);
+    __syncthreads();
+    unsigned long long upto = chunk0 + nchunks; // chunks [chunk0, upto) count
+    if (stream_mode) {
+        if (fin_min != ~0ull && fin_min < bad_min) upto = fin_min + 1;                       // the stream ends in chunk fin_min
+        else if (bad_min != ~0ull && bad_min == last_chunk && st[bad_min - chunk0].msg == trunc_msg) upto = bad_min; // incomplete tail
+    }
+    unsigned long long t = 0;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) {
+        if (chunk0 + i < upto) t += st[i].out_bytes;
+        else if (meta) meta[i].out_bytes = 0;
+    }
+    atomicAdd(&total, t);
     __syncthreads();
     if (threadIdx.x == 0) {
         acc[0] += total;
-        if (acc[1] == 0 && bad_min != ~0ull) { acc[1] = bad_min + 1; acc[2] = (uint64_t)(int64_t)st[bad_min - chunk0].code; acc[3] = st[bad_min - chunk0].msg; }
+        if (stream_mode && upto != chunk0 + nchunks) {
+            if (fin_min != ~0ull && fin_min < bad_min) { acc[5] = fin_min + 1; acc[6] = st[fin_min - chunk0].used & 0x7fffffffu; }
+            else acc[7] = bad_min + 1;
+        } else if (acc[1] == 0 && bad_min != ~0ull) { acc[1] = bad_min + 1; acc[2] = (uint64_t)(int64_t)st[bad_min - chunk0].code; acc[3] = st[bad_min - chunk0].msg; }
+        else if (stream_mode && fin_min != ~0ull) { acc[5] = fin_min + 1; acc[6] = st[fin_min - chunk0].used & 0x7fffffffu; } // (the final block ends the last chunk)
     }
 }
 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
-                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st);
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets);
 
 } // namespace zgpu
 
@@ -759,8 +796,9 @@ void engine_collect(zgpu_engine *e);
 int engine_fail(zgpu_engine *e, int code, const char *msg);
 struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
+// stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used)
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
-                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets)
 {
     if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || (chunk_size > kChunkMax && !(chunk_size == kWholeStream && nchunks == 1)) ||
         (chunk_size == kWholeStream && in_bytes >= (1ull << 29)))
@@ -771,12 +809,15 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     InfStatus *status = static_cast<InfStatus *>(engine_scratch(e, (size_t)batch * sizeof(InfStatus) + 64));
     if (!status) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
     uint64_t *acc = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(status) + (((size_t)batch * sizeof(InfStatus) + 15) & ~(size_t)15));
-    ChunkMeta *meta = engine_meta(e, batch);
+    const uint64_t max_pieces = (out_cap >> 16) + 2;
+    const uint32_t cbatch_cap = (uint32_t)(max_pieces < 65536 ? max_pieces : 65536); // the checksum pass works on 64 KiB pieces of the OUTPUT
+    ChunkMeta *meta = engine_meta(e, batch > cbatch_cap ? batch : cbatch_cap);
     if (!meta) return engine_fail(e, ZGPU_MEM_ERROR, "inflate meta");
     uint8_t *slots = nullptr;
     if (compact) { slots = static_cast<uint8_t *>(engine_scratch2(e, (size_t)batch * kChunkMax + 256)); if (!slots) return engine_fail(e, ZGPU_MEM_ERROR, "inflate slots"); }
     res->adler32 = 1; res->crc32 = 0; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0; res->out_bytes = 0;
-    ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(uint64_t), st));
+    res->in_used = in_bytes; res->stream_end = 0; res->incomplete = 0;
+    ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 8 * sizeof(uint64_t), st));
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
     static bool opt_in = false;
@@ -788,8 +829,8 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
         hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
-                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e));
-        hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc);
+                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), stream_mode);
+        hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc, stream_mode, nchunks - 1, compact ? meta : nullptr, (uint32_t)kMsgTruncated);
         if (compact) {
             launch_scan(meta, nb, c0, oscr, engine_run_state(e), out_cap, st); // out_bytes -> byte offsets, continuing across batches
             launch_stitch(slots, meta, oscr, c0, nb, d_out, out_cap, kChunkMax, st);
@@ -797,9 +838,13 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
         ZGPU_HIP_CHECK(hipGetLastError());
     }
     prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
-    uint64_t h[5];
+    uint64_t h[8];
     ZGPU_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    if (stream_mode) {
+        if (h[5]) { res->stream_end = 1; res->in_used = (h_offsets ? h_offsets[h[5] - 1] : 0) + h[6]; }
+        else if (h[7]) { res->incomplete = 1; res->in_used = h_offsets ? h_offsets[h[7] - 1] : 0; }
+    }
     res->out_bytes = h[0]; res->first_bad_chunk = h[1] ? (int32_t)(h[1] - 1) : -1; res->error_code = (int32_t)(int64_t)h[2]; res->error_msg = (uint32_t)h[3];
     if (h[1]) { engine_collect(e); return engine_fail(e, res->error_code, kInfMessages[res->error_msg < kMsgCount ? res->error_msg : 0]); }
     if (h[0] > out_cap) { engine_collect(e); return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small"); }
@@ -807,8 +852,9 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     const uint64_t npieces = h[0] ? (h[0] + kChunkMax - 1) / kChunkMax : 1;
     rs = RunStateHostI{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    for (uint64_t c0 = 0; c0 < npieces; c0 += batch) {
-        const uint32_t nb = (uint32_t)(npieces - c0 < batch ? npieces - c0 : batch);
+    const uint32_t cbatch = (uint32_t)(npieces < cbatch_cap ? npieces : cbatch_cap);
+    for (uint64_t c0 = 0; c0 < npieces; c0 += cbatch) {
+        const uint32_t nb = (uint32_t)(npieces - c0 < cbatch ? npieces - c0 : cbatch);
         ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
         launch_adler(g, meta, st);
@@ -848,12 +894,15 @@ hipStream_t engine_stream(zgpu_engine *e);
 // Decode a raw deflate body made of full-flush-separated segments without a side table.  Candidate boundaries are the
 // marker positions; a candidate that is not a real boundary (the pattern can occur inside stored or coded data) makes its
 // segment fail to decode and is merged away.  On success *offsets_out (optional) receives the validated boundaries.
-static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap, zgpu_inflate_result *res,
+// flags & ZGPU_INF_STREAM: `in` is the rest of a stream, not a delimited body: it ends where its final block ends (res->in_used,
+// res->stream_end) whatever follows, and input that stops inside a block yields the segments before it (res->incomplete).
+static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap, zgpu_inflate_result *res,
                                std::vector<uint64_t> *offsets_out)
 {
     if (!e || !in || !res || in_bytes == 0) return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
     hipStream_t st = engine_stream(e);
+    const uint32_t stream_mode = (flags & ZGPU_INF_STREAM) ? 1u : 0u;
     const uint64_t max_cand = in_bytes / 5 + 2;
     int rc = engine_ensure_stage(e, in_bytes + 64 + (max_cand + 2) * 2 * sizeof(uint64_t) + 64, out_cap ? out_cap : 1);
     if (rc) return rc;
@@ -874,24 +923,34 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
     std::sort(b.begin() + 1, b.begin() + 1 + ncand);
     b[ncand + 1] = in_bytes;
     b.erase(std::unique(b.begin(), b.end()), b.end()); // a marker can end exactly at the end of the body
-    for (;;) {
+    // A candidate that is not a boundary costs one more pass over the input; streams of other producers (sync-flushed protocols put a
+    // marker behind every message and keep the window across it) can hold thousands that are none.  So: a few passes that merge the
+    // failing segment into its successor, then -- and at once when a segment fails in the way a kept window looks (a distance that
+    // reaches back before the segment, more than 64 KiB of output) -- the stream is decoded from end to end by one workgroup.
+    bool whole = false;
+    for (int pass = 0;; pass++) {
         const uint64_t nseg = b.size() - 1;
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st);
+        rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st, stream_mode, b.data());
         if (rc == ZGPU_OK) break;
-        if (rc == ZGPU_DATA_ERROR && res->first_bad_chunk >= 0 && (uint64_t)res->first_bad_chunk + 1 < nseg) {
-            b.erase(b.begin() + res->first_bad_chunk + 1); // not a boundary after all: merge with the next segment
-            continue;
-        }
-        // The last segment does not decode on its own.  A body that simply stops early is reported as such; anything else may
-        // be a stream that was not produced in independent chunks (segments longer than 64 KiB, distances that reach back
-        // across what looked like a boundary): one workgroup decodes it from end to end, and its verdict is the stream's.
-        if (rc != ZGPU_DATA_ERROR || res->error_msg == kMsgTruncated || in_bytes >= (1ull << 29)) return rc;
+        if (rc != ZGPU_DATA_ERROR) return rc;
+        const bool last_bad = res->first_bad_chunk >= 0 && (uint64_t)res->first_bad_chunk + 1 == nseg;
+        if (last_bad && res->error_msg == kMsgTruncated) return rc; // the body stops early (strict mode; stream mode reports it as incomplete)
+        const bool window_kept = res->error_msg == kMsgTooFar || res->error_msg == kMsgOutput;
+        if (!last_bad && !window_kept && pass < 4) { b.erase(b.begin() + res->first_bad_chunk + 1); continue; } // not a boundary after all
+        if (in_bytes >= (1ull << 29)) return rc;
+        whole = true;
+        break;
+    }
+    if (whole) {
         b.assign({0, in_bytes});
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        rc = inflate_run(e, d_in, in_bytes, d_offs, 1, kWholeStream, engine_stage_out(e), out_cap, res, st);
-        if (rc != ZGPU_OK) return rc;
-        break;
+        rc = inflate_run(e, d_in, in_bytes, d_offs, 1, kWholeStream, engine_stage_out(e), out_cap, res, st, stream_mode, b.data());
+        if (rc != ZGPU_OK) {
+            // stream mode: input that stops inside a block is not an error, nothing of it is taken (one workgroup cannot hand a window on)
+            if (stream_mode && rc == ZGPU_DATA_ERROR && res->error_msg == kMsgTruncated) { res->incomplete = 1; res->in_used = 0; res->out_bytes = 0; res->stream_end = 0; return ZGPU_OK; }
+            return rc;
+        }
     }
     if (out && res->out_bytes) ZGPU_HIP_CHECK(hipMemcpy(out, engine_stage_out(e), res->out_bytes, hipMemcpyDeviceToHost));
     if (offsets_out) *offsets_out = b;
@@ -908,7 +967,7 @@ int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_by
     if (!offsets || !nchunks) return ZGPU_STREAM_ERROR;
     std::vector<uint64_t> b;
     zgpu_inflate_result res{};
-    int rc = inflate_stream_host(e, in, in_bytes, nullptr, max_chunks * (uint64_t)kChunkMax, &res, &b);
+    int rc = inflate_stream_host(e, in, in_bytes, 0, nullptr, max_chunks * (uint64_t)kChunkMax, &res, &b);
     if (rc) return rc;
     if (b.size() - 1 > max_chunks) return engine_fail(e, ZGPU_BUF_ERROR, "offset table too small");
     for (size_t i = 0; i < b.size(); i++) offsets[i] = b[i];
@@ -918,7 +977,12 @@ int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_by
 int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap, zgpu_inflate_result *res)
 {
     if (!out) return ZGPU_STREAM_ERROR;
-    return inflate_stream_host(e, in, in_bytes, out, out_cap, res, nullptr);
+    return inflate_stream_host(e, in, in_bytes, 0, out, out_cap, res, nullptr);
+}
+int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap, zgpu_inflate_result *res)
+{
+    if (!out) return ZGPU_STREAM_ERROR;
+    return inflate_stream_host(e, in, in_bytes, flags, out, out_cap, res, nullptr);
 }
 #pragma GCC visibility pop
 }

@@ -49,16 +49,19 @@ static zgpu_engine *engine_get(void)
 }
 
 /* ---- small utilities ---- */
-static const char *const k_errmsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
-                                         "insufficient memory", "buffer error", "incompatible version", ""};
+EXPORT const char *const z_errmsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
+                                         "insufficient memory", "buffer error", "incompatible version", ""}; /* zutil.c:14-24 */
+#define k_errmsg z_errmsg
 #define ERR_MSG(code) ((char *)k_errmsg[2 - (code)])
 
 EXPORT const char *zlibVersion(void) { return ZLIB_VERSION; }
 EXPORT const char *zError(int err) { return k_errmsg[2 - err]; }
 EXPORT uLong zlibCompileFlags(void) { return 0xa9; /* sizes of uInt/uLong/voidpf/z_off_t as the reference reports on LP64 */ }
 
-static voidpf default_alloc(voidpf opaque, uInt items, uInt size) { (void)opaque; return malloc((size_t)items * size); }
-static void default_free(voidpf opaque, voidpf p) { (void)opaque; free(p); }
+EXPORT voidpf zcalloc(voidpf opaque, unsigned items, unsigned size) { (void)opaque; return malloc((size_t)items * size); } /* zutil.c:300-308 */
+EXPORT void zcfree(voidpf opaque, voidpf p) { (void)opaque; free(p); }                                                   /* zutil.c:310-316 */
+#define default_alloc zcalloc
+#define default_free zcfree
 
 typedef struct { uint8_t *p; size_t len, cap; } bytebuf;
 static int buf_reserve(bytebuf *b, size_t extra)
@@ -111,11 +114,13 @@ static uint32_t adler_join(uint32_t x, uint32_t y, uint64_t leny)
 
 /* ---- CRC-32 (crc32.c:219-266 bytewise with one table; crc32_combine :370-423 as polynomial arithmetic mod P) ---- */
 static uint32_t g_crc_table[256];
+static uLong g_crc_table_ul[256]; /* the same values in the type get_crc_table() hands out */
 static pthread_once_t g_crc_once = PTHREAD_ONCE_INIT;
 static void crc_table_init(void)
 {
-    for (uint32_t i = 0; i < 256; i++) { uint32_t r = i; for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ 0xedb88320u : r >> 1; g_crc_table[i] = r; }
+    for (uint32_t i = 0; i < 256; i++) { uint32_t r = i; for (int k = 0; k < 8; k++) r = (r & 1u) ? (r >> 1) ^ 0xedb88320u : r >> 1; g_crc_table[i] = r; g_crc_table_ul[i] = r; }
 }
+EXPORT const uLongf *get_crc_table(void) { pthread_once(&g_crc_once, crc_table_init); return g_crc_table_ul; } /* crc32.c:205-213: the bytewise table */
 EXPORT uLong crc32(uLong crc, const Bytef *buf, uInt len)
 {
     if (buf == Z_NULL) return 0;
@@ -146,21 +151,35 @@ EXPORT uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2)
 enum { KIND_DEFLATE = 0x5a44, KIND_INFLATE = 0x5a49 };
 enum { ST_INIT = 1, ST_BUSY = 2, ST_FINISH = 3, ST_DONE = 4, ST_BAD = 5 };
 
+enum { IN_HEAD = 1, IN_BODY = 2, IN_TRAIL = 3, IN_DONE = 4 }; /* inflate: where the stream stands */
+
 struct internal_state {
     int kind, status, wrap, level, strategy, last_flush;
-    bytebuf in;       /* deflate: input not yet compressed;  inflate: compressed bytes not yet decoded */
+    bytebuf in;       /* deflate: input not yet compressed;  inflate: received bytes, consumed up to in_pos */
     bytebuf out;      /* produced bytes not yet handed to the caller */
     size_t out_pos;   /* first undelivered byte of out */
     int trailer_done; /* deflate: Adler trailer already appended */
     int any_block;    /* deflate: at least one chunk has been emitted */
     uint32_t adler;   /* Adler-32 of the uncompressed data that went through the GPU (deflate) / was produced (inflate) */
     uint32_t crc;     /* the same for CRC-32 (gzip wrapper, wrap == 2) */
-    int decoded;      /* inflate: the body has been decoded */
-    size_t next_try;  /* inflate: do not re-try a decode before this many bytes have been collected */
     bytebuf dict;     /* preset dictionary: deflate, the bytes the window receives until the first chunk is out; inflate, as set */
     int dict_pending; /* deflate: the first chunk has not been compressed yet and starts behind the dictionary */
     int need_dict, have_dict; /* inflate: the header asked for one / one has been set */
     uint32_t dictid;  /* Adler-32 of the dictionary (header field, deflate.c:646-649, inflate.c:623-627) */
+    gz_headerp gzhead; /* deflateSetHeader / inflateGetHeader */
+    int tuned; uint32_t tune[4]; /* deflateTune: good_length, max_lazy, nice_length, max_chain */
+    /* inflate */
+    int mode;         /* IN_* */
+    size_t in_pos;    /* first byte of `in` that has not been consumed */
+    int gz;           /* the stream is a gzip member (wrap & 2 and the magic was there) */
+    uint64_t produced; /* bytes decoded so far (ISIZE check) */
+    size_t next_try;  /* do not try to decode again before this many unconsumed bytes have been collected */
+    int pending_err;  /* a data error found behind output that has not been delivered yet: reported when it has */
+    const char *pending_msg;
+    int no_partial;   /* keep everything from in_pos until the stream ends in one decode (inflatePrime) */
+    int prime_bits; uint32_t prime_val; /* inflatePrime */
+    int sync_have;    /* inflateSync: bytes of 00 00 FF FF matched so far */
+    int at_marker;    /* the last decode consumed up to a flush marker (inflateSyncPoint) */
 };
 
 static uLong bound_for(uLong n)
@@ -236,6 +255,7 @@ EXPORT int deflateReset(z_streamp strm)
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->data_type = Z_UNKNOWN;
     s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0; s->dict.len = 0; s->dict_pending = 0;
+    s->tuned = 0; /* lm_init: the level's own parameters again (deflate.c:380, 1009-1012) */
     s->status = s->wrap ? ST_INIT : ST_BUSY; s->last_flush = Z_NO_FLUSH;
     s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
     return Z_OK;
@@ -275,9 +295,52 @@ EXPORT int deflateParams(z_streamp strm, int level, int strategy)
         rc = run_chunks(strm, s->in.p, s->in.len, 0);
         s->in.len = 0;
     }
+    if (s->level != level) s->tuned = 0; /* deflate.c:443-448 */
     s->level = level; s->strategy = strategy;
     return rc;
 }
+
+/* deflate.c:453-470 */
+EXPORT int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    s->tuned = 1; s->tune[0] = (uint32_t)good_length; s->tune[1] = (uint32_t)max_lazy; s->tune[2] = (uint32_t)nice_length; s->tune[3] = (uint32_t)max_chain;
+    return Z_OK;
+}
+/* deflate.c:404-413.  A stream that starts inside a byte moves the alignment padding of every stored block and of the flush
+ * marker of the first chunk; the chunk kernels start at a byte boundary, so only the trivial request is served. */
+EXPORT int deflatePrime(z_streamp strm, int bits, int value)
+{
+    (void)value;
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
+    return bits == 0 ? Z_OK : Z_STREAM_ERROR;
+}
+/* deflate.c:393-401 */
+EXPORT int deflateSetHeader(z_streamp strm, gz_headerp head)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE || strm->state->wrap != 2) return Z_STREAM_ERROR;
+    strm->state->gzhead = head;
+    return Z_OK;
+}
+static int buf_dup(bytebuf *d, const bytebuf *src) { d->p = NULL; d->len = d->cap = 0; return src->len == 0 || buf_put(d, src->p, src->len); }
+/* deflate.c:894-947 / inflate.c:1323-1368: an independent copy of the stream with everything it holds */
+static int state_copy(z_streamp dest, z_streamp source, int kind)
+{
+    if (source == Z_NULL || dest == Z_NULL || source->state == Z_NULL || source->state->kind != kind) return Z_STREAM_ERROR;
+    const struct internal_state *ss = source->state;
+    *dest = *source;
+    struct internal_state *ds = (struct internal_state *)dest->zalloc(dest->opaque, 1, (uInt)sizeof *ds);
+    if (!ds) return Z_MEM_ERROR;
+    *ds = *ss;
+    dest->state = ds;
+    if (!buf_dup(&ds->in, &ss->in) || !buf_dup(&ds->out, &ss->out) || !buf_dup(&ds->dict, &ss->dict)) {
+        free(ds->in.p); free(ds->out.p); free(ds->dict.p); dest->zfree(dest->opaque, ds); dest->state = Z_NULL;
+        return Z_MEM_ERROR;
+    }
+    return Z_OK;
+}
+EXPORT int deflateCopy(z_streamp dest, z_streamp source) { return state_copy(dest, source, KIND_DEFLATE); }
 
 /* level 0 needs no match finder or entropy coder: stored blocks are framing.  One chunk = the bytes the reference's
  * deflate_stored emits for a fresh stream of that chunk (deflate.c:1390-1439): blocks of at most 65531 bytes, the rest,
@@ -330,7 +393,9 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
             zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, 0};
             zgpu_deflate_result r;
             pthread_mutex_lock(&g_lock);
+            zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
             int rc = zgpu_deflate_dict_chunk_host(e, w.p, (uint32_t)w.len, (uint32_t)s->dict.len, &p, s->out.p + s->out.len, cap, &r);
+            zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
             pthread_mutex_unlock(&g_lock);
             free(w.p);
             if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
@@ -358,7 +423,9 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
     zgpu_deflate_result r;
     pthread_mutex_lock(&g_lock);
+    zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
     int rc = zgpu_deflate_host(e, src, n, &p, s->out.p + s->out.len, cap, NULL, &r);
+    zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
     pthread_mutex_unlock(&g_lock);
     if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
     s->out.len += r.out_bytes;
@@ -380,9 +447,23 @@ EXPORT int deflate(z_streamp strm, int flush)
     int old_flush = s->last_flush;
     s->last_flush = flush;
 
-    if (s->status == ST_INIT && s->wrap == 2) { /* gzip header without a gz_header, deflate.c:578-596; OS_CODE 3 as the reference builds on this host */
-        const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 4 : 0), 3};
-        if (!buf_put(&s->out, h, 10)) return Z_MEM_ERROR;
+    if (s->status == ST_INIT && s->wrap == 2) { /* gzip header, deflate.c:578-621 and the EXTRA/NAME/COMMENT/HCRC states :660-754; OS_CODE 3 as the reference builds on this host */
+        const uint8_t xfl = (uint8_t)(s->level == 9 ? 2 : (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 4 : 0);
+        const size_t h0 = s->out.len;
+        const gz_headerp g = s->gzhead;
+        if (g == Z_NULL) {
+            const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, xfl, 3};
+            if (!buf_put(&s->out, h, 10)) return Z_MEM_ERROR;
+        } else {
+            const uint8_t h[10] = {31, 139, 8, (uint8_t)((g->text ? 1 : 0) + (g->hcrc ? 2 : 0) + (g->extra == Z_NULL ? 0 : 4) + (g->name == Z_NULL ? 0 : 8) + (g->comment == Z_NULL ? 0 : 16)),
+                                   (uint8_t)g->time, (uint8_t)(g->time >> 8), (uint8_t)(g->time >> 16), (uint8_t)(g->time >> 24), xfl, (uint8_t)g->os};
+            int ok = buf_put(&s->out, h, 10);
+            if (ok && g->extra != Z_NULL) { const uint8_t xl[2] = {(uint8_t)g->extra_len, (uint8_t)(g->extra_len >> 8)}; ok = buf_put(&s->out, xl, 2) && buf_put(&s->out, g->extra, g->extra_len & 0xffffu); }
+            if (ok && g->name != Z_NULL) ok = buf_put(&s->out, g->name, strlen((const char *)g->name) + 1);
+            if (ok && g->comment != Z_NULL) ok = buf_put(&s->out, g->comment, strlen((const char *)g->comment) + 1);
+            if (ok && g->hcrc) { const uint32_t hc = (uint32_t)crc32(0, s->out.p + h0, (uInt)(s->out.len - h0)); const uint8_t c2[2] = {(uint8_t)hc, (uint8_t)(hc >> 8)}; ok = buf_put(&s->out, c2, 2); }
+            if (!ok) return Z_MEM_ERROR;
+        }
         s->status = ST_BUSY;
     }
     if (s->status == ST_INIT) { /* zlib header, deflate.c:625-649 */
@@ -486,7 +567,9 @@ EXPORT int inflateReset(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->adler = 1;
-    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->decoded = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0; s->dict.len = 0; s->need_dict = 0; s->have_dict = 0;
+    s->in.len = 0; s->in_pos = 0; s->out.len = 0; s->out_pos = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0; s->dict.len = 0;
+    s->need_dict = 0; s->have_dict = 0; s->mode = s->wrap ? IN_HEAD : IN_BODY; s->gz = 0; s->produced = 0; s->pending_err = 0; s->pending_msg = NULL;
+    s->no_partial = 0; s->prime_bits = 0; s->prime_val = 0; s->sync_have = 0; s->at_marker = 0; s->gzhead = Z_NULL;
     return Z_OK;
 }
 EXPORT int inflateEnd(z_streamp strm)
@@ -508,85 +591,137 @@ EXPORT int inflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
     s->have_dict = 1; s->need_dict = 0;
     return Z_OK;
 }
+/* inflate.c:1305-1321 */
+EXPORT int inflateGetHeader(z_streamp strm, gz_headerp head)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE || (strm->state->wrap & 2) == 0) return Z_STREAM_ERROR;
+    strm->state->gzhead = head;
+    head->done = 0;
+    return Z_OK;
+}
+EXPORT int inflateCopy(z_streamp dest, z_streamp source) { return state_copy(dest, source, KIND_INFLATE); }
+/* inflate.c:128-142: bits in front of the first input byte.  Served for raw streams before any input (what it exists for: a
+ * deflate stream that starts inside a byte); such a stream is decoded in one piece when its end has arrived. */
+EXPORT int inflatePrime(z_streamp strm, int bits, int value)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (bits < 0 || bits > 16 || s->prime_bits + bits > 32) return Z_STREAM_ERROR;
+    if (bits == 0) return Z_OK;
+    if (s->wrap != 0 || s->in.len != 0 || s->produced != 0 || s->prime_bits + bits > 24) return Z_STREAM_ERROR;
+    s->prime_val |= ((uint32_t)value & ((1u << bits) - 1)) << s->prime_bits;
+    s->prime_bits += bits; s->no_partial = 1;
+    return Z_OK;
+}
 
-/* Decode everything collected in s->in.  Returns Z_OK when decoded, Z_BUF_ERROR when the stream is visibly incomplete,
- * Z_DATA_ERROR / Z_MEM_ERROR otherwise.  out_hint: how much room the caller said it has (sizes the first attempt). */
-static int decode_all(z_streamp strm, size_t out_hint)
+#define IN_AVAIL(s) ((s)->in.len - (s)->in_pos)
+#define IN_PTR(s) ((s)->in.p + (s)->in_pos)
+static int in_bad(z_streamp strm, const char *msg) { strm->msg = (char *)msg; strm->state->status = ST_BAD; return Z_DATA_ERROR; }
+
+/* the wrapper in front of the deflate data (inflate.c:589-632 zlib, :596-602 and :634-759 gzip).  Z_OK: consumed, the body follows;
+ * Z_BUF_ERROR: not all there yet (nothing consumed); Z_NEED_DICT; Z_DATA_ERROR. */
+static int parse_header(z_streamp strm)
 {
     struct internal_state *s = strm->state;
-    const uint8_t *p = s->in.p; size_t n = s->in.len, skip = 0;
-    int gz = 0;
-    if ((s->wrap & 2) && n >= 2 && p[0] == 31 && p[1] == 139) { /* gzip header, inflate.c:596-602, 634-759 */
-        gz = 1;
+    const uint8_t *p = IN_PTR(s); const size_t n = IN_AVAIL(s);
+    size_t skip;
+    if (n < 2) return Z_BUF_ERROR;
+    if ((s->wrap & 2) && p[0] == 31 && p[1] == 139) {
         if (n < 10) return Z_BUF_ERROR;
-        if (p[2] != Z_DEFLATED) { strm->msg = (char *)"unknown compression method"; return Z_DATA_ERROR; }
-        if (p[3] & 0xe0) { strm->msg = (char *)"unknown header flags set"; return Z_DATA_ERROR; }
+        if (p[2] != Z_DEFLATED) return in_bad(strm, "unknown compression method");
+        if (p[3] & 0xe0) return in_bad(strm, "unknown header flags set");
         const unsigned flg = p[3];
+        size_t xoff = 0, xlen = 0, noff = 0, coff = 0;
         skip = 10;
-        if (flg & 4) { if (n < skip + 2) return Z_BUF_ERROR; skip += 2 + ((size_t)p[skip] | ((size_t)p[skip + 1] << 8)); if (n < skip) return Z_BUF_ERROR; }
-        if (flg & 8) { while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
-        if (flg & 16) { while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
+        if (flg & 4) { if (n < skip + 2) return Z_BUF_ERROR; xlen = (size_t)p[skip] | ((size_t)p[skip + 1] << 8); xoff = skip + 2; skip += 2 + xlen; if (n < skip) return Z_BUF_ERROR; }
+        if (flg & 8) { noff = skip; while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
+        if (flg & 16) { coff = skip; while (skip < n && p[skip]) skip++; if (skip >= n) return Z_BUF_ERROR; skip++; }
         if (flg & 2) {
             if (n < skip + 2) return Z_BUF_ERROR;
             const uint32_t hc = (uint32_t)crc32(0, p, (uInt)skip) & 0xffffu;
-            if (hc != ((uint32_t)p[skip] | ((uint32_t)p[skip + 1] << 8))) { strm->msg = (char *)"header crc mismatch"; return Z_DATA_ERROR; }
+            if (hc != ((uint32_t)p[skip] | ((uint32_t)p[skip + 1] << 8))) return in_bad(strm, "header crc mismatch");
             skip += 2;
         }
-        if (n < skip + 8 + 2) return Z_BUF_ERROR;
-    } else if (s->wrap) { /* inflate.c:589-632 */
-        if (n < 2) return Z_BUF_ERROR;
-        if (!(s->wrap & 1) || (((unsigned)p[0] << 8) + p[1]) % 31) { strm->msg = (char *)"incorrect header check"; return Z_DATA_ERROR; }
-        if ((p[0] & 15) != Z_DEFLATED) { strm->msg = (char *)"unknown compression method"; return Z_DATA_ERROR; }
-        if ((unsigned)(p[0] >> 4) + 8 > (unsigned)s->level) { strm->msg = (char *)"invalid window size"; return Z_DATA_ERROR; }
+        gz_headerp g = s->gzhead;
+        if (g != Z_NULL) { /* inflate.c:651-751 */
+            g->text = (int)(flg & 1); g->time = (uLong)p[4] | ((uLong)p[5] << 8) | ((uLong)p[6] << 16) | ((uLong)p[7] << 24);
+            g->xflags = p[8]; g->os = p[9]; g->hcrc = (int)((flg >> 1) & 1);
+            if (flg & 4) { g->extra_len = (uInt)xlen; if (g->extra != Z_NULL) memcpy(g->extra, p + xoff, xlen < g->extra_max ? xlen : g->extra_max); }
+            else g->extra = Z_NULL;
+            if (flg & 8) { if (g->name != Z_NULL && g->name_max) { size_t l = strlen((const char *)p + noff) + 1; memcpy(g->name, p + noff, l < g->name_max ? l : g->name_max); } }
+            else g->name = Z_NULL;
+            if (flg & 16) { if (g->comment != Z_NULL && g->comm_max) { size_t l = strlen((const char *)p + coff) + 1; memcpy(g->comment, p + coff, l < g->comm_max ? l : g->comm_max); } }
+            else g->comment = Z_NULL;
+            g->done = 1;
+        }
+        s->gz = 1; strm->adler = 0; /* the running check of a gzip member is its CRC-32 (inflate.c:602) */
+    } else {
+        if (!(s->wrap & 1) || (((unsigned)p[0] << 8) + p[1]) % 31) return in_bad(strm, "incorrect header check");
+        if ((p[0] & 15) != Z_DEFLATED) return in_bad(strm, "unknown compression method");
+        if ((unsigned)(p[0] >> 4) + 8 > (unsigned)s->level) return in_bad(strm, "invalid window size");
         skip = 2;
+        if (s->gzhead != Z_NULL) s->gzhead->done = -1; /* inflate.c:605 */
         if (p[1] & 0x20) { /* DICTID follows the header, inflate.c:617-627 */
             if (n < 6) return Z_BUF_ERROR;
             s->dictid = ((uint32_t)p[2] << 24) | ((uint32_t)p[3] << 16) | ((uint32_t)p[4] << 8) | p[5];
             if (!s->have_dict) { strm->adler = s->dictid; s->need_dict = 1; return Z_NEED_DICT; }
             skip = 6;
         }
-        if (n < skip + 4 + 2) return Z_BUF_ERROR;
+        s->gz = 0;
     }
-    const size_t tail = gz ? 8 : s->wrap ? 4 : 0;
-    size_t body = n - skip - tail;
-    if (body == 0) return Z_BUF_ERROR;
+    s->in_pos += skip;
+    s->mode = IN_BODY;
+    return Z_OK;
+}
+
+/* Decode what has been collected behind in_pos as far as it goes.  Z_OK: progress or nothing to do yet; errors as usual. */
+static int decode_some(z_streamp strm, size_t out_hint)
+{
+    struct internal_state *s = strm->state;
+    const size_t n = IN_AVAIL(s);
+    if (n == 0) return Z_OK;
     zgpu_engine *e = engine_get();
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
-    size_t cap = out_hint > body * 4 ? out_hint : body * 4;
+    const uint8_t *src = IN_PTR(s); size_t srcn = n;
+    uint8_t *shifted = NULL;
+    if (s->prime_bits) { /* the stream as the decoder must see it: the primed bits, then the input */
+        shifted = (uint8_t *)malloc(n + 5);
+        if (!shifted) return Z_MEM_ERROR;
+        uint64_t hold = s->prime_val; int nb = s->prime_bits; size_t o = 0;
+        for (size_t i = 0; i < n; i++) { hold |= (uint64_t)src[i] << nb; nb += 8; while (nb >= 8) { shifted[o++] = (uint8_t)hold; hold >>= 8; nb -= 8; } }
+        if (nb) shifted[o++] = (uint8_t)hold;
+        src = shifted; srcn = o;
+    }
+    size_t cap = out_hint > srcn * 4 ? out_hint : srcn * 4;
     if (cap < 65536) cap = 65536;
+    zgpu_inflate_result r;
     for (;;) {
-        s->out.len = 0; s->out_pos = 0;
-        if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
-        zgpu_inflate_result r;
+        if (!buf_reserve(&s->out, cap)) { free(shifted); return Z_MEM_ERROR; }
         memset(&r, 0, sizeof r);
+        const int first = s->produced == 0 && s->have_dict; /* the dictionary is what the window holds in front of the first byte only */
         pthread_mutex_lock(&g_lock);
-        int rc = zgpu_inflate_set_dictionary(e, s->have_dict ? s->dict.p : NULL, s->have_dict ? (uint32_t)s->dict.len : 0u);
-        if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host(e, p + skip, body, s->out.p, cap, &r);
-        if (s->have_dict) zgpu_inflate_set_dictionary(e, NULL, 0);
+        int rc = zgpu_inflate_set_dictionary(e, first ? s->dict.p : NULL, first ? (uint32_t)s->dict.len : 0u);
+        if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host2(e, src, srcn, ZGPU_INF_STREAM, s->out.p + s->out.len, cap, &r);
+        if (first) zgpu_inflate_set_dictionary(e, NULL, 0);
         pthread_mutex_unlock(&g_lock);
-        if (rc == ZGPU_BUF_ERROR) { cap = r.out_bytes > cap ? (size_t)r.out_bytes : cap * 4; if (cap > ((size_t)1 << 40)) return Z_MEM_ERROR; continue; }
-        if (rc == ZGPU_DATA_ERROR) {
-            /* a body that stops inside a block is what a not-yet-complete stream looks like */
-            const char *m = zgpu_inflate_message(r.error_msg);
-            if (strcmp(m, "segment ends inside a block") == 0) return Z_BUF_ERROR;
-            strm->msg = (char *)m; return Z_DATA_ERROR;
-        }
+        if (rc == ZGPU_BUF_ERROR) { cap = r.out_bytes > cap ? (size_t)r.out_bytes : cap * 4; if (cap > ((size_t)1 << 40)) { free(shifted); return Z_MEM_ERROR; } continue; }
+        free(shifted);
+        if (rc == ZGPU_DATA_ERROR) return in_bad(strm, zgpu_inflate_message(r.error_msg));
         if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
-        s->out.len = r.out_bytes; s->adler = gz ? r.crc32 : r.adler32; /* strm->adler is the CRC for a gzip stream (inflate.c:602) */
         break;
     }
-    if (gz) { /* inflate.c:1083-1112: CRC-32, then the length mod 2^32, both least significant byte first */
-        const uint8_t *t = p + n - 8;
-        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-        const uint32_t wlen = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-        if (want != s->adler) { strm->msg = (char *)"incorrect data check"; s->out.len = 0; return Z_DATA_ERROR; }
-        if (wlen != (uint32_t)s->out.len) { strm->msg = (char *)"incorrect length check"; s->out.len = 0; return Z_DATA_ERROR; }
-    } else if (s->wrap) { /* inflate.c:1077-1098 */
-        const uint8_t *t = p + n - 4;
-        uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
-        if (want != s->adler) { strm->msg = (char *)"incorrect data check"; s->out.len = 0; return Z_DATA_ERROR; }
+    if (s->no_partial && !r.stream_end) { s->next_try = n + n / 4 + 1; return Z_OK; } /* (all or nothing) */
+    if (r.out_bytes) {
+        s->out.len += r.out_bytes;
+        if (s->gz) s->crc = crc_join(s->crc, r.crc32, r.out_bytes); else s->adler = adler_join(s->adler, r.adler32, r.out_bytes);
+        s->produced += r.out_bytes;
     }
-    s->decoded = 1;
+    size_t used = (size_t)r.in_used;
+    if (s->prime_bits) { used = used * 8 > (size_t)s->prime_bits ? (used * 8 - (size_t)s->prime_bits + 7) / 8 : 0; if (used > n) used = n; s->prime_bits = 0; }
+    if (used >= 4) { const uint8_t *q = IN_PTR(s) + used - 4; s->at_marker = !r.stream_end && q[0] == 0 && q[1] == 0 && q[2] == 0xff && q[3] == 0xff; }
+    s->in_pos += used;
+    if (r.stream_end) s->mode = s->wrap ? IN_TRAIL : IN_DONE;
+    else s->next_try = IN_AVAIL(s) + IN_AVAIL(s) / 4 + 1;
     return Z_OK;
 }
 
@@ -599,30 +734,88 @@ EXPORT int inflate(z_streamp strm, int flush)
     if (s->status == ST_BAD) return Z_DATA_ERROR;
     if (s->status == ST_DONE) return Z_STREAM_END;
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
-    if (!s->decoded) {
-        if (strm->avail_in) {
-            if (!buf_put(&s->in, strm->next_in, strm->avail_in)) return Z_MEM_ERROR;
-            strm->next_in += strm->avail_in; strm->total_in += strm->avail_in; strm->avail_in = 0;
+    if (s->mode != IN_DONE && strm->avail_in) {
+        if (s->in_pos && s->in_pos >= s->in.len / 2) { memmove(s->in.p, s->in.p + s->in_pos, s->in.len - s->in_pos); s->in.len -= s->in_pos; s->in_pos = 0; }
+        if (!buf_put(&s->in, strm->next_in, strm->avail_in)) return Z_MEM_ERROR;
+        strm->next_in += strm->avail_in; strm->total_in += strm->avail_in; strm->avail_in = 0;
+    }
+    if (s->mode == IN_HEAD) {
+        int rc = parse_header(strm);
+        if (rc == Z_NEED_DICT || rc == Z_DATA_ERROR) return rc;
+    }
+    if (s->mode == IN_BODY && !s->pending_err) {
+        /* Decode when the caller says this is everything (Z_FINISH), has stopped supplying input, or enough has arrived since the
+         * last look.  What is complete is taken; a stream that stops inside a block simply waits for more. */
+        if (flush == Z_FINISH || in0 == 0 || IN_AVAIL(s) < 4096 || IN_AVAIL(s) >= s->next_try) {
+            int rc = decode_some(strm, strm->avail_out);
+            if (rc == Z_DATA_ERROR && s->out.len - s->out_pos != 0) { /* what was decoded before comes out first (inflate.c delivers as it goes) */
+                s->status = ST_BUSY; s->pending_err = 1; s->pending_msg = strm->msg; strm->msg = Z_NULL;
+            } else if (rc != Z_OK) return rc;
         }
-        /* Decode when the caller says this is everything (Z_FINISH) or has stopped supplying input.  A stream that is
-         * not complete yet reads as "ends inside a block" and simply waits for more input. */
-        if (flush == Z_FINISH || in0 == 0 || s->in.len < 4096 || s->in.len >= s->next_try) {
-            int rc = decode_all(strm, strm->avail_out);
-            if (rc == Z_BUF_ERROR) s->next_try = s->in.len + s->in.len / 4 + 1;
-            if (rc == Z_DATA_ERROR || rc == Z_MEM_ERROR || rc == Z_NEED_DICT || rc == Z_STREAM_ERROR) { if (rc == Z_DATA_ERROR) s->status = ST_BAD; return rc; }
-            if (rc == Z_BUF_ERROR) { /* incomplete: inflate.c:1150-1151 */
-                if (flush == Z_FINISH || (in0 == 0 && out0 == strm->avail_out)) return Z_BUF_ERROR;
-                return Z_OK;
+    }
+    if (s->mode == IN_TRAIL && !s->pending_err) { /* inflate.c:1077-1112 */
+        const size_t need = s->gz ? 8 : 4;
+        if (IN_AVAIL(s) >= need) {
+            const uint8_t *t = IN_PTR(s);
+            const char *bad = NULL;
+            if (s->gz) {
+                const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t wlen = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                if (want != s->crc) bad = "incorrect data check";
+                else if (wlen != (uint32_t)s->produced) bad = "incorrect length check";
+            } else {
+                const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+                if (want != s->adler) bad = "incorrect data check";
             }
+            if (bad) { s->pending_err = 1; s->pending_msg = bad; }
+            else { s->in_pos += need; s->mode = IN_DONE; }
         }
     }
-    if (s->decoded) {
-        deliver(strm);
-        strm->adler = s->adler;
-        if (s->out.len - s->out_pos == 0) { s->status = ST_DONE; return Z_STREAM_END; }
-        if (flush == Z_FINISH) return Z_BUF_ERROR; /* output space ran out (inflate.c:1150-1151) */
+    deliver(strm);
+    strm->adler = s->gz ? s->crc : s->adler;
+    const int drained = s->out.len - s->out_pos == 0;
+    if (s->pending_err && drained) return in_bad(strm, s->pending_msg);
+    if (s->mode == IN_DONE && drained) {
+        /* inflate.c:1114: the rest of the input stays with the caller -- as far as it came with this call */
+        size_t back = IN_AVAIL(s);
+        if (back > in0) back = in0;
+        strm->next_in -= back; strm->avail_in += (uInt)back; strm->total_in -= back; s->in.len -= back;
+        s->status = ST_DONE;
+        return Z_STREAM_END;
     }
+    if (flush == Z_FINISH) return Z_BUF_ERROR; /* not all input, or not enough room (inflate.c:1150-1151) */
+    if (in0 == 0 && out0 == strm->avail_out) return Z_BUF_ERROR;
     return Z_OK;
+}
+
+/* one byte of the search for 00 00 FF FF (inflate.c:1245-1265): `have` bytes of the pattern matched so far */
+static int sync_step(int have, uint8_t c)
+{
+    if (c == (have < 2 ? 0 : 0xff)) return have + 1;
+    return c ? 0 : 4 - have; /* a zero where FF was due: the zeros seen so far may still open the pattern */
+}
+/* inflate.c:1239-1303: skip to the next full-flush point (00 00 FF FF) and go on from there as a fresh decoder */
+EXPORT int inflateSync(z_streamp strm)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (strm->avail_in == 0 && IN_AVAIL(s) == 0) return Z_BUF_ERROR;
+    int have = s->sync_have;
+    while (have < 4 && IN_AVAIL(s)) have = sync_step(have, s->in.p[s->in_pos++]); /* what was handed over before comes first */
+    while (have < 4 && strm->avail_in) { have = sync_step(have, *strm->next_in++); strm->avail_in--; strm->total_in++; }
+    if (have < 4) { s->sync_have = have; return Z_DATA_ERROR; }
+    /* total_in / total_out stay; everything else starts over in the middle of the deflate data (inflate.c:1296-1301) */
+    s->sync_have = 0; s->status = ST_BUSY; s->mode = IN_BODY; s->adler = 1; s->crc = 0; s->produced = 0; s->pending_err = 0; s->next_try = 0;
+    s->have_dict = 0; s->need_dict = 0; s->at_marker = 1; strm->msg = Z_NULL;
+    return Z_OK;
+}
+/* inflate.c:1313-1321: "at the end of a block generated by Z_SYNC_FLUSH or Z_FULL_FLUSH" -- here: the decoder has consumed the
+ * input up to and including a flush marker and nothing behind it */
+EXPORT int inflateSyncPoint(z_streamp strm)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return Z_STREAM_ERROR;
+    const struct internal_state *s = strm->state;
+    return s->mode == IN_BODY && s->at_marker && IN_AVAIL(s) == 0;
 }
 
 /* ======================================================================== one-shot wrappers (compress.c, uncompr.c) */
@@ -674,7 +867,7 @@ EXPORT int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong s
     if (err != Z_STREAM_END) {
         /* uncompr.c:50-56: a stream that ends early is a data error, an output buffer that is too small a buffer error.
          * This inflate() always consumes all input, so the two are told apart by whether the body could be decoded. */
-        const int decoded = st.state != Z_NULL && st.state->decoded;
+        const int decoded = st.state != Z_NULL && st.state->mode == IN_DONE; /* (the whole stream was there: the output buffer is what ran out) */
         inflateEnd(&st);
         if (err == Z_NEED_DICT || (err == Z_BUF_ERROR && !decoded)) return Z_DATA_ERROR;
         return err == Z_OK ? Z_BUF_ERROR : err;
