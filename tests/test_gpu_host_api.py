@@ -100,7 +100,8 @@ def test_full_flush_points_become_chunk_boundaries():
     assert z == want
     # and the library reads its own flushed stream back, fed one byte at a time
     rc, back, msg, adler = Z.inflate_stream(z[:5000], 10, in_step=1)  # incomplete prefix: every byte is accepted, then a call
-    assert rc == Z.Z_BUF_ERROR and back == b""                        # without input or progress gets Z_BUF_ERROR (inflate.c:1150-1151)
+    assert rc == Z.Z_BUF_ERROR and back == data[:3]                   # without input or progress gets Z_BUF_ERROR (inflate.c:1150-1151);
+                                                                      # what the complete segments in front hold has come out (here: the first flush point)
     rc, back, msg, adler = Z.inflate_stream(z, len(data), in_step=4096)
     assert rc == Z.Z_STREAM_END and back == data and adler == O.adler32(data)
 

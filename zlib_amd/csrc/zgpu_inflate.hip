@@ -367,6 +367,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
             drop(b, pos & 31);
         };
         bool last = false, seen_final = false;
+        uint32_t org_bits = 0; // bits between the segment's (aligned) start and the bit reader's origin: stored blocks move the origin
         CodeRows lrows{}, drows{}; // per-length rows of the two codes of the current block (lanes 1..15)
         INF_T(0);
         while (!err && !last && !stop) {
@@ -392,6 +393,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                 const uint32_t np = bytepos + len;
                 b.d0 += np >> 2; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
                 b.seg_bits -= (np & ~3u) * 8; // seg_bits stays relative to the origin
+                org_bits += (np & ~3u) * 8;   // ... and this is where the origin stands in the segment
                 wave_sync();
                 stage_fill(b, L.stage, lane); wave_sync();
                 prime(b, L.stage);
@@ -575,7 +577,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
             else if (stream_mode && seen_final) { }                           // stream mode: the stream ends where its final block ends, whatever follows
             else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
             else if (((b.seg_bits - used) >> 3) != 0) err = kMsgTrailing;     // whole bytes left over
-            if (!err && lane == 0) { L.end_bits = used; L.end_final = seen_final ? 1u : 0u; }
+            if (!err && lane == 0) { L.end_bits = org_bits + used - lead * 8; L.end_final = seen_final ? 1u : 0u; } // counted from the segment's first byte
         }
 #ifdef ZGPU_INF_DEBUG2
         if (err && lane == 0) printf("chunk %u reader err %u consumed %u seg_bits %u rd %u filled %u bits %u\n", c, err, consumed_bits(b), b.seg_bits, b.rd, b.filled, b.bits);
