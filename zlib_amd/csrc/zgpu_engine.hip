@@ -28,7 +28,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
-                const uint64_t *h_offsets = nullptr);
+                const uint64_t *h_offsets = nullptr, bool open_end = false);
 
 } // namespace zgpu
 

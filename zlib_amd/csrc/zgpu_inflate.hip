@@ -780,7 +780,8 @@ __global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *s
 }
 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
-                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets);
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets,
+                bool open_end = false);
 
 } // namespace zgpu
 
@@ -798,10 +799,12 @@ void engine_collect(zgpu_engine *e);
 int engine_fail(zgpu_engine *e, int code, const char *msg);
 struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
-// stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used)
+// stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used);
+// open_end: the last segment ends with a flush marker like the others, no segment has to hold the final block
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
-                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets)
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets, bool open_end)
 {
+    const uint64_t last_chunk = open_end ? ~0ull : nchunks - 1;
     if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || (chunk_size > kChunkMax && !(chunk_size == kWholeStream && nchunks == 1)) ||
         (chunk_size == kWholeStream && in_bytes >= (1ull << 29)))
         return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
@@ -830,9 +833,9 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
-        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, nchunks - 1, chunk_size,
+        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
                            compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), stream_mode);
-        hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc, stream_mode, nchunks - 1, compact ? meta : nullptr, (uint32_t)kMsgTruncated);
+        hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc, stream_mode, last_chunk, compact ? meta : nullptr, (uint32_t)kMsgTruncated);
         if (compact) {
             launch_scan(meta, nb, c0, oscr, engine_run_state(e), out_cap, st); // out_bytes -> byte offsets, continuing across batches
             launch_stitch(slots, meta, oscr, c0, nb, d_out, out_cap, kChunkMax, st);
@@ -930,13 +933,18 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
     // failing segment into its successor, then -- and at once when a segment fails in the way a kept window looks (a distance that
     // reaches back before the segment, more than 64 KiB of output) -- the stream is decoded from end to end by one workgroup.
     bool whole = false;
+    // stream mode: input that ends with a flush marker may simply be all there is so far -- then the last segment is a segment like the
+    // others and none of them has to hold the final block
+    const uint8_t *hin = static_cast<const uint8_t *>(in);
+    bool open_end = stream_mode && in_bytes >= 4 && hin[in_bytes - 4] == 0 && hin[in_bytes - 3] == 0 && hin[in_bytes - 2] == 0xFF && hin[in_bytes - 1] == 0xFF;
     for (int pass = 0;; pass++) {
         const uint64_t nseg = b.size() - 1;
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st, stream_mode, b.data());
+        rc = inflate_run(e, d_in, in_bytes, d_offs, nseg, 0, engine_stage_out(e), out_cap, res, st, stream_mode, b.data(), open_end);
         if (rc == ZGPU_OK) break;
         if (rc != ZGPU_DATA_ERROR) return rc;
         const bool last_bad = res->first_bad_chunk >= 0 && (uint64_t)res->first_bad_chunk + 1 == nseg;
+        if (open_end && last_bad && res->error_msg == kMsgTruncated) { open_end = false; pass--; continue; } // (the marker was data: an incomplete tail after all)
         if (last_bad && res->error_msg == kMsgTruncated) return rc; // the body stops early (strict mode; stream mode reports it as incomplete)
         const bool window_kept = res->error_msg == kMsgTooFar || res->error_msg == kMsgOutput;
         if (!last_bad && !window_kept && pass < 4) { b.erase(b.begin() + res->first_bad_chunk + 1); continue; } // not a boundary after all

@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
         bool fresh = false;
         if (st == W_READY) { // start the search at x with the match in hand (length handL, 2: none) as the seed
             const uint32_t seed = handL, idx = irx & 0xffffu, rank = irx >> 16, budget = seed >= cfg.good ? (chainQ ? chainQ : 0xffffu) : chainF; // (a quarter of fewer than 4 never runs out, deflate.c:1163)
-            uint32_t avail = x < npos ? (rank < budget ? rank : budget) : 0;
+            uint32_t avail = (x < npos && seed < cfg.lazy) ? (rank < budget ? rank : budget) : 0; // (deflate.c:1588: no search once the match in hand reaches max_lazy)
             irn = x + 1 < npos ? ir[x + 1] : 0;
             if (seed >= kMinMatch) { const uint32_t E = handM + handL; irE = E < npos ? ir[E] : 0; haveE = true; }
             const int w = (int)(x + base);

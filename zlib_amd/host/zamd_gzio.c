@@ -39,7 +39,10 @@ typedef struct {
     int last;         /* reading: the pushed-back byte is the last one of the data */
     int level, strategy;
     int started;      /* reading: the header of the first member has been looked at */
+    uint8_t *carry;   /* reading: input behind the end of a member that inflate() had taken in already, in front of the file's next bytes */
 } gz_file;
+
+void zamd_inflate_rest(z_streamp strm, const unsigned char **p, size_t *n); /* zamd_zlib.c */
 
 static int gz_destroy(gz_file *s)
 {
@@ -49,7 +52,7 @@ static int gz_destroy(gz_file *s)
     if (s->strm.state != Z_NULL) err = s->mode == 'w' ? deflateEnd(&s->strm) : inflateEnd(&s->strm);
     if (s->fp != NULL && fclose(s->fp)) err = Z_ERRNO;
     if (s->err < 0) err = s->err;
-    free(s->buf); free(s->path); free(s);
+    free(s->buf); free(s->carry); free(s->path); free(s);
     return err;
 }
 
@@ -100,7 +103,7 @@ EXPORT gzFile gzdopen(int fd, const char *mode)
 /* ------------------------------------------------------------------ reading */
 static void gz_fill(gz_file *s) /* more compressed bytes behind what next_in still holds */
 {
-    if (s->eof) return;
+    if (s->eof || s->strm.avail_in > GZ_BUF / 2) return; /* (a carried-over tail can be longer than the buffer: it is used up first) */
     if (s->strm.avail_in && s->strm.next_in != s->buf) memmove(s->buf, s->strm.next_in, s->strm.avail_in);
     s->strm.next_in = s->buf;
     errno = 0;
@@ -183,6 +186,18 @@ EXPORT int gzread(gzFile file, voidp buf, unsigned len)
         }
         if (rc != Z_STREAM_END) { s->err = rc; break; }
         /* the member is complete: CRC and length, then maybe another member (gzio.c:459-476) */
+        {   /* what inflate() took in beyond the end of the deflate data in earlier calls comes first */
+            const unsigned char *rest; size_t nrest;
+            zamd_inflate_rest(&s->strm, &rest, &nrest);
+            if (nrest) {
+                uint8_t *c = (uint8_t *)malloc(nrest + s->strm.avail_in + 1);
+                if (!c) { s->err = Z_MEM_ERROR; break; }
+                memcpy(c, rest, nrest);
+                if (s->strm.avail_in) memcpy(c + nrest, s->strm.next_in, s->strm.avail_in);
+                free(s->carry); s->carry = c;
+                s->strm.next_in = c; s->strm.avail_in += (uInt)nrest; s->in -= (z_off_t)nrest;
+            }
+        }
         s->crc = crc32(s->crc, start, (uInt)(s->strm.next_out - start));
         s->out += (z_off_t)(s->strm.next_out - start);
         start = s->strm.next_out;

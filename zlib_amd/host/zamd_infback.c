@@ -14,7 +14,9 @@
 #define EXPORT __attribute__((visibility("default")))
 #define KIND_BACK 0x5a42
 
-struct back_state { int kind; z_stream inner; unsigned char *window; unsigned wsize; };
+struct back_state { int kind; z_stream inner; unsigned char *window; unsigned wsize; unsigned char *carry; };
+
+void zamd_inflate_rest(z_streamp strm, const unsigned char **p, size_t *n); /* zamd_zlib.c */
 
 EXPORT int inflateBackInit_(z_streamp strm, int windowBits, unsigned char *window, const char *version, int stream_size)
 {
@@ -53,7 +55,20 @@ EXPORT int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, 
             z->next_out = b->window; z->avail_out = b->wsize;
             if (rc != Z_STREAM_END) continue; /* more may be waiting inside */
         }
-        if (rc == Z_STREAM_END) { strm->next_in = z->next_in; strm->avail_in = z->avail_in; return Z_STREAM_END; }
+        if (rc == Z_STREAM_END) { /* the unused input: what the decoder had taken in beyond the end, then what the last piece still holds */
+            const unsigned char *rest; size_t nrest;
+            zamd_inflate_rest(z, &rest, &nrest);
+            strm->next_in = z->next_in; strm->avail_in = z->avail_in;
+            if (nrest) {
+                free(b->carry);
+                b->carry = (unsigned char *)malloc(nrest + z->avail_in + 1);
+                if (!b->carry) return Z_MEM_ERROR;
+                memcpy(b->carry, rest, nrest);
+                if (z->avail_in) memcpy(b->carry + nrest, z->next_in, z->avail_in);
+                strm->next_in = b->carry; strm->avail_in = (uInt)(nrest + z->avail_in);
+            }
+            return Z_STREAM_END;
+        }
         if (rc == Z_DATA_ERROR || rc == Z_MEM_ERROR || rc == Z_STREAM_ERROR || rc == Z_NEED_DICT) {
             if (z->avail_out != b->wsize) (void)out(out_desc, b->window, b->wsize - z->avail_out); /* what was decoded before the error */
             strm->msg = z->msg; strm->next_in = z->next_in; strm->avail_in = z->avail_in;
@@ -72,6 +87,7 @@ EXPORT int inflateBackEnd(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || ((struct back_state *)strm->state)->kind != KIND_BACK) return Z_STREAM_ERROR;
     struct back_state *b = (struct back_state *)strm->state;
     inflateEnd(&b->inner);
+    free(b->carry);
     free(b);
     strm->state = Z_NULL;
     return Z_OK;

@@ -788,6 +788,16 @@ EXPORT int inflate(z_streamp strm, int flush)
     return Z_OK;
 }
 
+/* Library-internal (zamd_gzio.c, zamd_infback.c): after Z_STREAM_END, the input this stream took in earlier calls that lies behind its
+ * end and could not be handed back through next_in (inflate() only gives back what came with the call that reached the end).  In
+ * stream order these bytes come BEFORE whatever next_in / avail_in hold now.  Valid until the next call on the stream. */
+__attribute__((visibility("hidden"))) void zamd_inflate_rest(z_streamp strm, const unsigned char **p, size_t *n)
+{
+    *p = Z_NULL; *n = 0;
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE || strm->state->mode != IN_DONE) return;
+    *p = IN_PTR(strm->state); *n = IN_AVAIL(strm->state);
+}
+
 /* one byte of the search for 00 00 FF FF (inflate.c:1245-1265): `have` bytes of the pattern matched so far */
 static int sync_step(int have, uint8_t c)
 {
