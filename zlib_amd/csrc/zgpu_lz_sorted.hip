@@ -672,8 +672,14 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 #ifndef ZGPU_WBLK
 #define ZGPU_WBLK 64 // positions per block
 #endif
-constexpr uint32_t kWThreads = 512, kWWaves = kWThreads / 64, kWBlk = ZGPU_WBLK, kWTrig = ZGPU_WTRIG;
-constexpr uint32_t kWNeuBytes = kChunkMax / 8;
+#ifndef ZGPU_WTHREADS
+#define ZGPU_WTHREADS 512
+#endif
+#ifndef ZGPU_WNEU_SHIFT
+#define ZGPU_WNEU_SHIFT 0 // walkers meet at positions that are multiples of 1 << this (fewer bits in LDS, a little more duplicate work)
+#endif
+constexpr uint32_t kWThreads = ZGPU_WTHREADS, kWWaves = kWThreads / 64, kWBlk = ZGPU_WBLK, kWTrig = ZGPU_WTRIG, kWNeuShift = ZGPU_WNEU_SHIFT;
+constexpr uint32_t kWNeuBytes = (kChunkMax >> kWNeuShift) / 8;
 constexpr uint32_t kWLds = kM3DataLds + 16 + kWNeuBytes + kWWaves * kM3WaveLds;
 static_assert(2 * kWLds <= 160 * 1024, "two walker workgroups per CU");
 enum : uint32_t { W_NEED = 0, W_LIMBO = 1, W_READY = 2, W_SEARCH = 3, W_DONE = 4 };
@@ -697,17 +703,21 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_time(unsi
     hipMemcpyFromSymbol(out, HIP_SYMBOL(walk_time), sizeof z);
     if (reset) hipMemcpyToSymbol(HIP_SYMBOL(walk_time), z, sizeof z);
 }
-#define W_T0() unsigned long long wt_prev = __builtin_readcyclecounter(), wt_fold = 0
-#define W_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&walk_time[i], t_ - wt_prev - ((i) == 1 ? wt_fold : 0)); if ((i) == 1 && lane == 0) atomicAdd(&walk_time[2], wt_fold); wt_fold = 0; wt_prev = t_; } while (0)
+// (summed in registers, written once when the wave is done: an atomic per section would sit in the wave's memory counter and be waited for
+// by the next section that needs a load)
+#define W_T0() unsigned long long wt_prev = __builtin_readcyclecounter(), wt_fold = 0, wt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define W_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); wt_acc[i] += t_ - wt_prev - ((i) == 1 ? wt_fold : 0); if ((i) == 1) wt_acc[2] += wt_fold; wt_fold = 0; wt_prev = t_; } while (0)
 #define W_TF(stmt) do { const unsigned long long f0_ = __builtin_readcyclecounter(); stmt; wt_fold += __builtin_readcyclecounter() - f0_; } while (0)
+#define W_TEND() do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&walk_time[i_], wt_acc[i_]); } while (0)
 #else
 #define W_T0() do { } while (0)
 #define W_T(i) do { } while (0)
 #define W_TF(stmt) stmt
+#define W_TEND() do { } while (0)
 #endif
 __device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
 
-__global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
+__global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
                                                             uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -725,7 +735,8 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
     uint32_t *gm = gm_all + (size_t)c * kChunkMax, *gs = gs_all + (size_t)c * (kChunkMax / 32);
     const uint32_t npos = n >= 3 ? n - 2 : 0, base = chunk_base(g, c);
     stage_chunk<kWThreads>(src, n, d32, tid);
-    for (uint32_t i = tid; i < kChunkMax / 32; i += kWThreads) { NEU[i] = 0; gs[i] = 0; }
+    for (uint32_t i = tid; i < kChunkMax / 32; i += kWThreads) { if (i < kWNeuBytes / 4) NEU[i] = 0; gs[i] = 0; }
+    if (tid < 8) d32[(kChunkMax + 64) / 4 + tid] = 0xffffffffu; // the word the quick check reads where a zero word would look like a hit
     if (tid == 0) ctrl[0] = 0;
     __syncthreads();
     int slide_at; // visited positions >= slide_at see the slid window (ParseCtx::slide_at, zgpu_lz_parse.hip)
@@ -747,7 +758,8 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
     // its coalesced loads) left every body waiting for memory.  So a pass fetches the first 32 candidates of the searches it
     // starts at once (F0..F3; most chains are no longer), the lanes take them over one body later (G0..G3, consumed by rotation),
     // and a chain that goes on after 32 candidates is refilled by the next pass.
-    int thr = 0, thr_next = 0, gi = -(int)kSPad; // gi: S index of the next group to fetch
+    int gi = -(int)kSPad; // gi: S index of the next group to fetch
+    uint32_t firstb = 0; // 1 << 22 while the lane's search has not examined its first candidate (the one the reference allows at MAX_DIST exactly)
     uint4 G0 = make_uint4(0, 0, 0, 0), G1 = G0, G2 = G0, G3 = G0, F0 = G0, F1 = G0, F2 = G0, F3 = G0;
     uint32_t left = 0;  // groups in G0..G3
     bool cont = false;  // out of candidates in registers, chain not finished
@@ -762,6 +774,10 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             const uint32_t e = lds_ld32(ring + ((tail + lane) << 2));
             const uint32_t q = e & 0xffffu, o = (e >> 16) & 63u;
             const uint32_t po = lds_ld16(pw + o * 2), look = n - po, cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
+            // the candidate must be in reach: the first one of a chain at most MAX_DIST back (deflate.c:1588), the others strictly less
+            // (deflate.c:1163), none at the NIL position.  Positions descend along a chain, so refusing them here one by one is the
+            // reference's "the chain ends at the first candidate out of reach".
+            const bool reach = po - q <= kMaxDist - ((e >> 22) & 1u ? 0u : 1u) && q + base >= 1u;
             uint32_t l = 0, xa, xb;
             for (;;) { // eight bytes of both strings per round trip
                 lds_cmp8(dbase + q + l, dbase + po + l, xa, xb);
@@ -770,7 +786,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             }
             uint32_t len = xa ? l + ((uint32_t)__builtin_ctz(xa) >> 3) : xb ? l + 4 + ((uint32_t)__builtin_ctz(xb) >> 3) : l + 8;
             len = len < cap ? len : cap;
-            if (len >= kMinMatch) lds_max32(slot + o * 4, len >= nice ? (0x80000000u | (q << 9) | len) : ((len << 16) | q));
+            if (len >= kMinMatch && reach) lds_max32(slot + o * 4, len >= nice ? (0x80000000u | (q << 9) | len) : ((len << 16) | q));
         }
         const uint32_t key = lds_ld32(slot + lane * 4);
         if (key != key_seen) {
@@ -822,8 +838,9 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
         if (toN) { // neutral at y
             st = W_NEED;
             if (y < n) {
-                const uint32_t bit = 1u << (y & 31u);
-                if (!(atomicOr(&NEU[y >> 5], bit) & bit)) { // nobody has been here: go on
+                const uint32_t yc = y >> kWNeuShift, bit = 1u << (yc & 31u);
+                const bool meet = (y & ((1u << kWNeuShift) - 1u)) == 0; // (elsewhere walkers pass each other unseen: the same work twice, the same result)
+                if (!meet || !(atomicOr(&NEU[yc >> 5], bit) & bit)) { // nobody has been here: go on
                     x = y;
                     if (haveIr) { irx = irY; st = W_READY; }
                     else { irl = y < npos ? ir[y] : 0; st = W_LIMBO; W_STAT(7, 1); }
@@ -842,8 +859,8 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                     const uint32_t b = b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
                     if (b >= nblk) st = W_DONE;
                     else {
-                        const uint32_t y2 = b * kWBlk, bit = 1u << (y2 & 31u);
-                        if (!(atomicOr(&NEU[y2 >> 5], bit) & bit)) { x = y2; handL = kMinMatch - 1; irl = y2 < npos ? ir[y2] : 0; st = W_LIMBO; }
+                        const uint32_t y2 = b * kWBlk, bit = 1u << ((y2 >> kWNeuShift) & 31u);
+                        if (!(atomicOr(&NEU[(y2 >> kWNeuShift) >> 5], bit) & bit)) { x = y2; handL = kMinMatch - 1; irl = y2 < npos ? ir[y2] : 0; st = W_LIMBO; }
                         // (else: a walker from further down passed through here; the next pass asks for another block)
                     }
                 }
@@ -856,16 +873,13 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             uint32_t avail = (x < npos && seed < cfg.lazy) ? (rank < budget ? rank : budget) : 0; // (deflate.c:1588: no search once the match in hand reaches max_lazy)
             irn = x + 1 < npos ? ir[x + 1] : 0;
             if (seed >= kMinMatch) { const uint32_t E = handM + handL; irE = E < npos ? ir[E] : 0; haveE = true; }
-            const int w = (int)(x + base);
-            thr = (w - (int)kMaxDist > 1 ? w - (int)kMaxDist : 1) - (int)base;              // first candidate: dist <= MAX_DIST, not NIL (deflate.c:1588)
-            thr_next = (w - (int)kMaxDist + 1 > 1 ? w - (int)kMaxDist + 1 : 1) - (int)base;  // later ones: strictly inside (deflate.c:1163)
             // the one position whose first candidate can sit at window index 32768: NIL after the slide (deflate.c:1309-1312)
             if (x + base == kWSize + kMaxDist && avail != 0 && (int)x >= slide_at && (uint32_t)S[idx - 1] + base == kWSize) avail = 0;
             best = seed; sentinel = (seed << 16) | 0xffffu; key_seen = sentinel; boff = dbase + best - 1;
             scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 16);
             lds_st32(slot + lane * 4, sentinel);
             lds_st16(pw + lane * 2, x);
-            rem = avail;
+            rem = avail; firstb = 1u << 22;
             gi = (int)idx - 8;
             st = W_SEARCH;
             fresh = avail != 0;
@@ -882,7 +896,7 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
             gi -= 32;
         }
         W_T(0);
-        if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(st != W_DONE) == 0) { W_TEND(); break; }
         const unsigned long long smask = __builtin_amdgcn_ballot_w64(st == W_SEARCH);
         const uint32_t idle = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(st == W_LIMBO || st == W_NEED));
 
@@ -893,8 +907,13 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                 W_STAT(0, 1);
                 // the quick-check bytes of all eight candidates in one round trip, read at the best length the body starts with: a fold
                 // inside the body moves best/boff/scan2 for the next body, the rest of this one goes on with what it read (walking with a
-                // stale best length is exact, see match3_kernel)
+                // stale best length is exact, see match3_kernel).  A lane examines nv = min(rem, 8) candidates; for the others of the
+                // group -- and for all eight in lanes that examine nothing -- it reads a fixed word whose two bytes differ from scan0, so
+                // that a hit is a hit of a real candidate and no step needs the walking mask (whether a candidate is in reach is
+                // checked when it is compared in full, fold()).
                 const uint32_t scan0 = scan2;
+                const uint32_t nv = sel_mask(amask0, rem < 8 ? rem : 8, 0u);
+                const uint32_t sent = dbase + (scan0 ? kChunkMax + 8u : kChunkMax + 64u + 8u); // zero pad | the 0xFF words behind it
                 uint32_t qv[8], bb[8];
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) {
@@ -902,8 +921,9 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                     qv[j] = (j & 1) ? wd & 0xffffu : wd >> 16;
                 }
                 {
-                    uint32_t a0 = boff + qv[0], a1 = boff + qv[1], a2 = boff + qv[2], a3 = boff + qv[3], a4 = boff + qv[4], a5 = boff + qv[5], a6 = boff + qv[6], a7 = boff + qv[7];
-                    uint32_t hi[8]; // (d16 loads would fill both halves of one register, but with SRAM ECC on they clear the other half)
+                    uint32_t a[8], hi[8]; // (d16 loads would fill both halves of one register, but with SRAM ECC on they clear the other half)
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) a[j] = j < nv ? boff + qv[j] : sent;
                     asm volatile("ds_read_u8 %0, %16\n\tds_read_u8 %8, %16 offset:1\n\tds_read_u8 %1, %17\n\tds_read_u8 %9, %17 offset:1\n\t"
                                  "ds_read_u8 %2, %18\n\tds_read_u8 %10, %18 offset:1\n\tds_read_u8 %3, %19\n\tds_read_u8 %11, %19 offset:1\n\t"
                                  "ds_read_u8 %4, %20\n\tds_read_u8 %12, %20 offset:1\n\tds_read_u8 %5, %21\n\tds_read_u8 %13, %21 offset:1\n\t"
@@ -911,24 +931,22 @@ __global__ void __launch_bounds__(kWThreads, 4) walk_kernel(ChunkGeom g, LevelCf
                                  "s_waitcnt lgkmcnt(0)"
                                  : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]), "=&v"(bb[4]), "=&v"(bb[5]), "=&v"(bb[6]), "=&v"(bb[7]),
                                    "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
-                                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "memory");
+                                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
 #pragma unroll
                     for (uint32_t j = 0; j < 8; j++) bb[j] |= hi[j] << 16;
                 }
+                W_STAT(1, __popcll(amask0) * 8);
 #pragma unroll
                 for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t q = qv[j];
-                    W_STAT(1, __popcll(amask));
-                    amask &= mask_le_i32(thr, (int)q); // beyond MAX_DIST (or the NIL position): the chain ends here
-                    if (j == 0) thr = (int)sel_mask(amask0, (uint32_t)thr_next, (uint32_t)thr);
-                    const unsigned long long m = amask & mask_eq_u32(bb[j], scan0);
+                    const unsigned long long m = mask_eq_u32(bb[j], scan0);
                     if (m) {
-                        stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, q | lanebits);
+                        stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, qv[j] | lanebits | (j == 0 ? firstb : 0u));
                         tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
                         if (tail >= 64) W_TF(fold());
                     }
-                    amask &= mask_gt_u32(rem, j + 1);
                 }
+                amask &= mask_gt_u32(rem, 8u); // lanes whose chain goes on (a fold may have ended others: nice_match)
+                firstb = sel_mask(amask0, 0u, firstb);
             }
             G0 = G1; G1 = G2; G2 = G3;
             left = left ? left - 1 : 0;
