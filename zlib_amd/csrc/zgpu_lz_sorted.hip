@@ -19,6 +19,8 @@
 //                       candidate in the same step, full compares deferred to a per-wave stack and folded with atomic max
 //   K3                  parse2_kernel (zgpu_lz_parse.hip), or parse_kernel of zgpu_lz_parallel.hip with ZGPU_PARSE=1
 #include "zgpu_common.h"
+#define ZGPU_PARSE_HEADER_ONLY
+#include "zgpu_lz_parse.h"
 #include <cstdlib>
 #include "../../include/zamd_gpu.h"
 
@@ -717,8 +719,13 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_time(unsi
 #endif
 __device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
 
+// FUSE: when its walkers are done the workgroup goes on with the rest of the parse itself (parse_chunk, zgpu_lz_parse.h, in the LDS the
+// chunk bytes lived in).  That part is all latency -- a window at a time, one wave threading the path -- and leaves the CU's vector
+// units to the other workgroup's walkers, which are bound by exactly those; as a kernel of its own it cost as much as a third of the walk.
+static_assert(kP2LdsBytes <= kM3DataLds, "the parse works in the memory of the chunk bytes");
+template <bool FUSE>
 __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
-                                                            uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all)
+                                                            uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all, uint32_t *__restrict__ tokens, ChunkMeta *meta)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *d32 = lds;
@@ -964,6 +971,20 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         }
         W_T(1);
     }
+    if (FUSE) {
+        __syncthreads(); // every walker of the chunk is done: gm / gs are complete (and written: the barrier waits for the stores)
+        constexpr uint32_t kP2Threads = kWThreads;
+        constexpr bool LITE = true, FUSED = true;
+        const uint2 *recs = nullptr;
+        const uint32_t *gmv_all = gm_all, *gsv_all = gs_all;
+        uint8_t *pl = reinterpret_cast<uint8_t *>(lds);
+        uint16_t *const J = reinterpret_cast<uint16_t *>(pl + kP2OffJ);
+        uint32_t *const HAS = reinterpret_cast<uint32_t *>(pl + kP2OffHAS), *const MARK = reinterpret_cast<uint32_t *>(pl + kP2OffMARK), *const COV = reinterpret_cast<uint32_t *>(pl + kP2OffCOV),
+                 *const MAT = reinterpret_cast<uint32_t *>(pl + kP2OffMAT), *const wbase = reinterpret_cast<uint32_t *>(pl + kP2OffWbase), *const VIS = reinterpret_cast<uint32_t *>(pl + kP2OffVIS),
+                 *const EXITS = reinterpret_cast<uint32_t *>(pl + kP2OffEXITS), *const wave_tot = reinterpret_cast<uint32_t *>(pl + kP2OffWtot);
+        uint32_t &sh_entry = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry);
+#include "zgpu_lz_parse_body.inc"
+    }
 }
 
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
@@ -996,9 +1017,20 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     prof_span_begin(prof, st, &ev);
     if (walk) { // the records' memory holds the walkers' output: gm (u32 per position), then the bitmaps gs (2048 words per chunk)
         uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
+        static int fuse = -1; // ZGPU_WALK_FUSE=0: the rest of the parse as a kernel of its own (A/B runs)
+        if (fuse < 0) { const char *v = getenv("ZGPU_WALK_FUSE"); fuse = v ? atoi(v) : 1; }
         static bool opt_inw = false;
-        if (!opt_inw) { hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds); opt_inw = true; }
-        hipLaunchKernelGGL(walk_kernel, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs);
+        if (!opt_inw) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+            opt_inw = true;
+        }
+        if (fuse) {
+            hipLaunchKernelGGL(walk_kernel<true>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
+            prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+            return;
+        }
+        hipLaunchKernelGGL(walk_kernel<false>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
         prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
         prof_span_begin(prof, st, &ev);
         launch_parse_lite(g, cfg, gm, gs, tokens, meta, st);
