@@ -5,9 +5,9 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rd -- python3 bench.py "$@" --no-cpu-baseline > $OUT/rd.log 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wr -- python3 bench.py "$@" --no-cpu-baseline > $OUT/wr.log 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 bench.py "$@" --no-cpu-baseline > $OUT/l2.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rd -- python3 bench.py "$@" --no-cpu-baseline --no-extras > $OUT/rd.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wr -- python3 bench.py "$@" --no-cpu-baseline --no-extras > $OUT/wr.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 bench.py "$@" --no-cpu-baseline --no-extras > $OUT/l2.log 2>&1 || exit 1
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys
 out = sys.argv[1]

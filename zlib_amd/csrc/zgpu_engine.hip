@@ -28,7 +28,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
-                const uint64_t *h_offsets = nullptr, bool open_end = false);
+                const uint64_t *h_offsets = nullptr, bool open_end = false, uint8_t *h_dst = nullptr);
 
 } // namespace zgpu
 
@@ -37,6 +37,8 @@ struct StageSpan { int stage; hipEvent_t a, b; };
 struct zgpu_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr; // H2D of the *_host entry points: the next batch's input moves while this batch's kernels run
+    std::vector<hipEvent_t> copy_ev;
     char err[512] = {0};
     // deflate workspace, sized for `batch_cap` chunks
     uint32_t batch_cap = 0;
@@ -161,9 +163,11 @@ static void zlib_header(int level, int strategy, uint8_t hdr[2]) // qcsrc/deflat
 }
 
 // d_seg (optional): device table of nseg+1 offsets; then every segment is one chunk and chunk_size is ignored.
+// h_src (optional, uniform chunking only): the input still lies in host memory; every batch's bytes are copied to d_in on the engine's
+// copy stream right before the batch's kernels are queued, so the copy of batch k+1 runs under the kernels of batch k.
 static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_seg, uint64_t nseg,
                           const zgpu_deflate_params *p, uint8_t *d_out, uint64_t out_cap, uint64_t *d_chunk_offsets,
-                          zgpu_deflate_result *res, hipStream_t st, uint32_t skip0 = 0)
+                          zgpu_deflate_result *res, hipStream_t st, uint32_t skip0 = 0, const uint8_t *h_src = nullptr)
 {
     if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
@@ -210,6 +214,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // chunks in flight to fill 256 CUs, so batches are as large as device memory allows (~1 MiB of workspace per chunk).
     uint32_t batch_max = env_u32("ZGPU_BATCH_CHUNKS", 65536); // (small values are for tests: several launches per call)
     if (batch_max == 0) batch_max = 1;
+    if (h_src && batch_max > 4096) batch_max = 4096; // host input: 256 MiB per batch, so that copies and kernels take turns often enough to overlap
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
@@ -245,9 +250,17 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 10, hipMemcpyHostToDevice, st));
     }
 
-    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
+    size_t nbatch = 0;
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch, nbatch++) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
         g.chunk0 = c0; g.nchunks = nb;
+        if (h_src && in_bytes) { // this batch's input: host -> device on the copy stream, the kernels below wait for it
+            const uint64_t lo = c0 * chunk_size, hi = (c0 + nb) * (uint64_t)chunk_size < in_bytes ? (c0 + nb) * (uint64_t)chunk_size : in_bytes;
+            while (e->copy_ev.size() <= nbatch) { hipEvent_t ev; ZGPU_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e->copy_ev.push_back(ev); }
+            ZGPU_HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(d_in) + lo, h_src + lo, hi - lo, hipMemcpyHostToDevice, e->copy_stream));
+            ZGPU_HIP_CHECK(hipEventRecord(e->copy_ev[nbatch], e->copy_stream));
+            ZGPU_HIP_CHECK(hipStreamWaitEvent(st, e->copy_ev[nbatch], 0));
+        }
         if (serial) {
             StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
@@ -276,7 +289,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     collect_spans(e);
     if (sort_fault) { // the LDS did not serve an atomic's lanes in lane order: redo the call with the sort that does not rely on it
         e->exact_sort = 1;
-        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st, skip0);
+        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st, skip0, h_src);
     }
     if (rs.overflow || (tail_bytes && out_cap < rs.out_total + tail_bytes)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
@@ -342,7 +355,7 @@ int zgpu_engine_create(int device, zgpu_engine **out)
     if (device < 0 || device >= n) return ZGPU_ERRNO;
     zgpu_engine *e = new zgpu_engine();
     e->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&e->run, 256) != hipSuccess) {
         delete e;
         return ZGPU_ERRNO;
@@ -359,6 +372,8 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
+    for (auto ev : e->copy_ev) hipEventDestroy(ev);
+    hipStreamDestroy(e->copy_stream);
     hipStreamDestroy(e->stream);
     delete e;
 }
@@ -415,8 +430,11 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
     const uint64_t bound = zgpu_deflate_bound(in_bytes, chunk_size);
     int rc = ensure_stage(e, in_bytes, bound);
     if (rc) return rc;
-    if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
-    rc = deflate_device(e, e->stage_in, in_bytes, nullptr, 0, p, e->stage_out, bound, nullptr, res, e->stream);
+    // (the copy stream must not run ahead of the previous call's kernels, which may still read the staging buffer: it starts behind them)
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    const bool overlap = in_bytes > (uint64_t)4096 * chunk_size; // (more than one batch: otherwise there is nothing to overlap the copy with)
+    if (!overlap && in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    rc = deflate_device(e, e->stage_in, in_bytes, nullptr, 0, p, e->stage_out, bound, nullptr, res, e->stream, 0, overlap ? static_cast<const uint8_t *>(in) : nullptr);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -481,10 +499,13 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->offsets, chunk_offsets, (nchunks + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-    rc = inflate_run(e, e->stage_in, in_bytes, e->offsets, nchunks, chunk_size, e->stage_out, need_out, res, e->stream);
+    // direct placement with room for every chunk: the output goes to the caller's buffer batch by batch, under the decoding of the next batch
+    const bool stream_out = chunk_size != 0 && chunk_size <= kChunkMax; // (copies stop at out_cap: a buffer that is too small is reported as before)
+    rc = inflate_run(e, e->stage_in, in_bytes, e->offsets, nchunks, chunk_size, e->stage_out, need_out, res, e->stream, 0, nullptr, false,
+                     stream_out ? static_cast<uint8_t *>(out) : nullptr);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
-    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (!stream_out) ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     return ZGPU_OK;
 }
@@ -614,6 +635,12 @@ const uint8_t *engine_inflate_dict(zgpu_engine *e) { return e->inf_dict; }
 uint32_t engine_inflate_dict_len(zgpu_engine *e) { return e->inf_dict_len; }
 int engine_ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes) { return ensure_stage(e, in_bytes, out_bytes); }
 hipStream_t engine_stream(zgpu_engine *e) { return e->stream; }
+hipStream_t engine_copy_stream(zgpu_engine *e) { return e->copy_stream; }
+hipEvent_t engine_copy_event(zgpu_engine *e, size_t i)
+{
+    while (e->copy_ev.size() <= i) { hipEvent_t ev; if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr; e->copy_ev.push_back(ev); }
+    return e->copy_ev[i];
+}
 ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch)
 {
     if (batch > e->inf_meta_cap) {

@@ -16,6 +16,7 @@
 #include "zgpu_common.h"
 #include "../../include/zamd_gpu.h"
 #include <cstdio>
+#include <cstdlib>
 
 struct zgpu_engine;
 
@@ -781,7 +782,7 @@ __global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *s
 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets,
-                bool open_end = false);
+                bool open_end = false, uint8_t *h_dst = nullptr);
 
 } // namespace zgpu
 
@@ -797,12 +798,17 @@ uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
 int engine_device(zgpu_engine *e);
 void engine_collect(zgpu_engine *e);
 int engine_fail(zgpu_engine *e, int code, const char *msg);
+hipStream_t engine_copy_stream(zgpu_engine *e);
+hipEvent_t engine_copy_event(zgpu_engine *e, size_t i);
 struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 // stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used);
 // open_end: the last segment ends with a flush marker like the others, no segment has to hold the final block
+// h_dst (direct placement only): the caller's host buffer; every batch's output is copied there on the engine's copy stream while the
+// next batch is being decoded
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
-                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets, bool open_end)
+                uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets, bool open_end,
+                uint8_t *h_dst)
 {
     const uint64_t last_chunk = open_end ? ~0ull : nchunks - 1;
     if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || (chunk_size > kChunkMax && !(chunk_size == kWholeStream && nchunks == 1)) ||
@@ -810,7 +816,12 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
         return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
     const bool compact = chunk_size == 0; // segments of any size: decode into slots, then concatenate
-    const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
+    // (one batch has nothing to overlap with; and the copy engine path of small pageable copies behind an event has thrown inside the runtime)
+    static long tohost_min = -1;
+    if (tohost_min < 0) { const char *v = getenv("ZGPU_TOHOST_MIN_CHUNKS"); tohost_min = v ? atol(v) : 4097; }
+    const bool to_host = h_dst && chunk_size != 0 && chunk_size <= kChunkMax && (long)nchunks >= tohost_min;
+    const uint32_t batch_cap = to_host ? 4096u : 65536u; // (host output: batches small enough for copies and kernels to take turns)
+    const uint32_t batch = (uint32_t)(nchunks < batch_cap ? nchunks : batch_cap);
     InfStatus *status = static_cast<InfStatus *>(engine_scratch(e, (size_t)batch * sizeof(InfStatus) + 64));
     if (!status) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
     uint64_t *acc = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(status) + (((size_t)batch * sizeof(InfStatus) + 15) & ~(size_t)15));
@@ -841,6 +852,22 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
             launch_stitch(slots, meta, oscr, c0, nb, d_out, out_cap, kChunkMax, st);
         }
         ZGPU_HIP_CHECK(hipGetLastError());
+        if (to_host) { // the batch before this one goes to the host while this one is being decoded (a copy to pageable memory holds the host)
+            const size_t b = (size_t)(c0 / batch);
+            ZGPU_HIP_CHECK(hipEventRecord(engine_copy_event(e, b), st));
+            if (b > 0) {
+                const uint64_t lo = (c0 - batch) * chunk_size, hi = c0 * (uint64_t)chunk_size < out_cap ? c0 * (uint64_t)chunk_size : out_cap;
+                ZGPU_HIP_CHECK(hipStreamWaitEvent(engine_copy_stream(e), engine_copy_event(e, b - 1), 0));
+                if (hi > lo) ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst + lo, d_out + lo, hi - lo, hipMemcpyDeviceToHost, engine_copy_stream(e)));
+            }
+        }
+    }
+    if (to_host) {
+        const size_t b = (size_t)((nchunks - 1) / batch);
+        const uint64_t lo = b * (uint64_t)batch * chunk_size, hi = nchunks * (uint64_t)chunk_size < out_cap ? nchunks * (uint64_t)chunk_size : out_cap;
+        ZGPU_HIP_CHECK(hipStreamWaitEvent(engine_copy_stream(e), engine_copy_event(e, b), 0));
+        if (hi > lo) ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst + lo, d_out + lo, hi - lo, hipMemcpyDeviceToHost, engine_copy_stream(e)));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(engine_copy_stream(e)));
     }
     prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
     uint64_t h[8];
@@ -871,6 +898,10 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     engine_collect(e);
     res->adler32 = rs.adler_a | (rs.adler_b << 16);
     res->crc32 = rs.crc;
+    if (h_dst && !to_host && h[0]) { // a host destination that was not served batch by batch
+        ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst, d_out, h[0], hipMemcpyDeviceToHost, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return ZGPU_OK;
 }
 } // namespace zgpu
