@@ -680,6 +680,10 @@ __global__ void __launch_bounds__(kM2Threads, 8) match3_kernel(ChunkGeom g, Leve
 #ifndef ZGPU_WNEU_SHIFT
 #define ZGPU_WNEU_SHIFT 0 // walkers meet at positions that are multiples of 1 << this (fewer bits in LDS, a little more duplicate work)
 #endif
+#ifndef ZGPU_WFOLD_AT
+#define ZGPU_WFOLD_AT 64 // parked candidates that make a wave compare them (at most 64 more arrive with one step: the stack holds 128)
+#endif
+constexpr uint32_t kWFoldAt = ZGPU_WFOLD_AT;
 constexpr uint32_t kWThreads = ZGPU_WTHREADS, kWWaves = kWThreads / 64, kWBlk = ZGPU_WBLK, kWTrig = ZGPU_WTRIG, kWNeuShift = ZGPU_WNEU_SHIFT;
 constexpr uint32_t kWNeuBytes = (kChunkMax >> kWNeuShift) / 8;
 constexpr uint32_t kWLds = kM3DataLds + 16 + kWNeuBytes + kWWaves * kM3WaveLds;
@@ -949,7 +953,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
                     if (m) {
                         stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, qv[j] | lanebits | (j == 0 ? firstb : 0u));
                         tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
-                        if (tail >= 64) W_TF(fold());
+                        if (tail >= kWFoldAt) W_TF(fold());
                     }
                 }
                 amask &= mask_gt_u32(rem, 8u); // lanes whose chain goes on (a fold may have ended others: nice_match)
