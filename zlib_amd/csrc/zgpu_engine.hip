@@ -316,6 +316,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     return ZGPU_OK;
 }
 
+ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch);
+uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
+
 static int ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes)
 {
     if (in_bytes > e->stage_in_cap) {
@@ -530,10 +533,10 @@ int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uin
     const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
     int rc = ensure_deflate_ws(e, 1, false, 1);
     if (rc) return rc;
-    ChunkMeta *meta = nullptr;
-    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&meta), (size_t)batch * sizeof(ChunkMeta)));
-    uint64_t *offs = nullptr;
-    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&offs), (nchunks + 1) * sizeof(uint64_t)));
+    // (the engine's grow-only scratch: these two are called per buffer by checksum-only users)
+    ChunkMeta *meta = engine_meta(e, batch);
+    uint64_t *offs = engine_offsets_scratch(e, nchunks + 1);
+    if (!meta || !offs) return fail(e, ZGPU_MEM_ERROR, "checksum scratch");
     RunStateHost rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
@@ -545,7 +548,6 @@ int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uin
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
-    hipFree(meta); hipFree(offs);
     *adler_out = rs.adler_a | (rs.adler_b << 16);
     return ZGPU_OK;
 }
@@ -559,10 +561,10 @@ int zgpu_crc32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint3
     const uint32_t batch = (uint32_t)(nchunks < 65536 ? nchunks : 65536);
     int rc = ensure_deflate_ws(e, 1, false, 1);
     if (rc) return rc;
-    ChunkMeta *meta = nullptr;
-    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&meta), (size_t)batch * sizeof(ChunkMeta)));
-    uint64_t *offs = nullptr;
-    ZGPU_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&offs), (nchunks + 1) * sizeof(uint64_t)));
+    // (the engine's grow-only scratch: these two are called per buffer by checksum-only users)
+    ChunkMeta *meta = engine_meta(e, batch);
+    uint64_t *offs = engine_offsets_scratch(e, nchunks + 1);
+    if (!meta || !offs) return fail(e, ZGPU_MEM_ERROR, "checksum scratch");
     RunStateHost rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
@@ -574,7 +576,6 @@ int zgpu_crc32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint3
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
-    hipFree(meta); hipFree(offs);
     *crc_out = rs.crc;
     return ZGPU_OK;
 }

@@ -1008,7 +1008,18 @@ int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_by
     if (!offsets || !nchunks) return ZGPU_STREAM_ERROR;
     std::vector<uint64_t> b;
     zgpu_inflate_result res{};
-    int rc = inflate_stream_host(e, in, in_bytes, 0, nullptr, max_chunks * (uint64_t)kChunkMax, &res, &b);
+    // the staging output is sized from the data (four times the input, more when the decode asks for it), not from the capacity of the
+    // caller's table: max_chunks * 64 KiB is 15 GB for the default table of a 1 MiB body
+    uint64_t cap = in_bytes * 4 + 65536;
+    const uint64_t cap_max = max_chunks * (uint64_t)kChunkMax;
+    if (cap > cap_max) cap = cap_max;
+    int rc;
+    for (;;) {
+        rc = inflate_stream_host(e, in, in_bytes, 0, nullptr, cap, &res, &b);
+        if (rc != ZGPU_BUF_ERROR || cap >= cap_max) break;
+        cap = res.out_bytes > cap ? res.out_bytes : cap * 4;
+        if (cap > cap_max) cap = cap_max;
+    }
     if (rc) return rc;
     if (b.size() - 1 > max_chunks) return engine_fail(e, ZGPU_BUF_ERROR, "offset table too small");
     for (size_t i = 0; i < b.size(); i++) offsets[i] = b[i];
