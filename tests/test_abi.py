@@ -128,3 +128,14 @@ def test_reference_example_links_with_host_library(tmp_path):
     subprocess.check_call(["gcc", "-std=gnu89", "-w", "-I/root/reference/h", ex, "-o", str(exe), "-L" + libdir, "-lzamd_z", "-lzamd_gpu",
                            "-Wl,-rpath," + libdir])
     assert exe.exists()
+
+
+def test_host_library_exports_the_zip_entry_points():
+    """include/zamd_zip.h: every zamd_zip_* / zamd_unzip_* it declares is exported."""
+    import subprocess
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zamd_zip.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(zamd_(?:un)?zip_[a-z_]+)\s*\(", text)))
+    assert len(names) == 9, names
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "zlib_amd", "libzamd_z.so")]).decode()
+    have = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert not [n for n in names if n not in have]
