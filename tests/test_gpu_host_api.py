@@ -84,6 +84,12 @@ def test_streaming_deflate_tiny_buffers():
     assert info["total_in"] == len(data) and info["total_out"] == len(want) and info["adler"] == O.adler32(data)
     z, codes, info = Z.deflate_stream(data[:70000], 1, [(70000, Z.Z_FINISH)], in_step=1000, out_step=None)
     assert z == O.deflate_stream(data[:70000], 1) and info["end_rc"] == Z.Z_OK
+    # input that ends exactly on a chunk boundary, fed in slices and finished with an empty call (minizip's zipWriteInFileInZip /
+    # zipCloseFileInZip, qcsrc/zip.c:969-1062): the last chunk carries the final bit, as in the one-call stream
+    for n in (65536, 131072):
+        for lvl in (1, 6):
+            z, codes, info = Z.deflate_stream(data[:n], lvl, [(n, Z.Z_NO_FLUSH), (0, Z.Z_FINISH)], in_step=16384, out_step=16384)
+            assert z == O.deflate_stream(data[:n], lvl), (n, lvl)
     small = cases.HELLO
     z, codes, info = Z.deflate_stream(small, 9, [(len(small), Z.Z_FINISH)], in_step=1, out_step=1)
     assert z == O.deflate_stream(small, 9)

@@ -10,8 +10,8 @@
  * inflate_fast()/inflate_table() -- to the GPU through zgpu_deflate_host() / zgpu_inflate_stream_host().
  * There is no CPU codec in this file.
  *
- * deflate(): input is collected until at least one 64 KiB chunk is complete (or a flush / finish asks for everything),
- * the complete chunks go to the GPU in one call, the compressed bytes are handed out through next_out as space
+ * deflate(): input is collected until at least one 64 KiB chunk is complete and has input behind it (or a flush / finish asks for
+ * everything), those chunks go to the GPU in one call, the compressed bytes are handed out through next_out as space
  * allows.  inflate(): compressed input is collected; whenever the caller signals the end (Z_FINISH) or stops
  * supplying input, everything collected so far is decoded on the GPU and delivered through next_out.
  */
@@ -493,21 +493,23 @@ EXPORT int deflate(z_streamp strm, int flush)
             /* the first chunk behind a dictionary is 65536 - |dictionary| bytes: collect until it is complete */
             const size_t room = CHUNK - s->dict.len;
             if (!buf_put(&s->in, src, n)) rc = Z_MEM_ERROR;
-            else if (s->in.len >= room) {
+            else if (s->in.len > room) {
                 rc = run_chunks(strm, s->in.p, room, 0);
                 memmove(s->in.p, s->in.p + room, s->in.len - room); s->in.len -= room;
-                if (rc == Z_OK && s->in.len >= CHUNK) {
-                    size_t whole = s->in.len - s->in.len % CHUNK;
+                if (rc == Z_OK && s->in.len > CHUNK) {
+                    size_t whole = (s->in.len - 1) / CHUNK * CHUNK;
                     rc = run_chunks(strm, s->in.p, whole, 0);
                     memmove(s->in.p, s->in.p + whole, s->in.len - whole); s->in.len -= whole;
                 }
             }
         } else if (flush == Z_NO_FLUSH) {
-            /* only complete chunks are compressed now; the tail waits for more input */
-            if (s->in.len == 0 && n >= CHUNK) { size_t whole = n - n % CHUNK; rc = run_chunks(strm, src, whole, 0); src += whole; n -= whole; }
+            /* only chunks with input behind them are compressed now: the tail waits for more input, and so does a chunk that is complete
+             * but may turn out to be the last one (it then carries the final bit instead of a flush marker and an empty final block --
+             * what the reference driven chunk by chunk writes, however the caller slices its input) */
+            if (s->in.len == 0 && n > CHUNK) { size_t whole = (n - 1) / CHUNK * CHUNK; rc = run_chunks(strm, src, whole, 0); src += whole; n -= whole; }
             if (rc == Z_OK && n) { if (!buf_put(&s->in, src, n)) rc = Z_MEM_ERROR; }
-            if (rc == Z_OK && s->in.len >= CHUNK) {
-                size_t whole = s->in.len - s->in.len % CHUNK;
+            if (rc == Z_OK && s->in.len > CHUNK) {
+                size_t whole = (s->in.len - 1) / CHUNK * CHUNK;
                 rc = run_chunks(strm, s->in.p, whole, 0);
                 memmove(s->in.p, s->in.p + whole, s->in.len - whole); s->in.len -= whole;
             }
