@@ -171,6 +171,12 @@ int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, 
 #define ZGPU_INF_STREAM 1u
 int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap,
                               zgpu_inflate_result *res);
+/* A body that does not split at flush markers and holds at least 128 KiB (ZGPU_SPEC_MIN_BYTES) is decoded in pieces all the same: block starts
+ * are searched behind every 1/4096 of the input (at least 32 KiB apart), every piece is decoded with the 32 KiB in front of it unknown,
+ * the chain of pieces is checked and the unknowns filled in afterwards (zgpu_inflate.hip, spec_*).  A stream whose pieces do
+ * not chain -- damaged, cut short, or one false block start -- goes through the one-workgroup decoder and gets its verdict.
+ * Diagnostics: how many streams this process decoded in pieces / sent to the one-workgroup decoder. */
+uint64_t zgpu_inflate_spec_count(int which); /* 0: decoded in pieces, 1: one-workgroup decodes */
 const char *zgpu_inflate_message(uint32_t index);
 /* Preset dictionary of the inflate calls that follow (inflateSetDictionary, qcsrc/inflate.c:1200-1236): the first segment of a
  * call may reach back into its last min(len, 32768) bytes.  Stays set until replaced; len 0 clears it. */

@@ -1,0 +1,124 @@
+"""SURVEY.md 8f N4 -- streams that were not produced in chunks (the system zlib's output) decoded in pieces: block starts found by
+search, every piece decoded with the window in front of it unknown, the chain of pieces checked, the unknowns filled in
+(zgpu_inflate.hip, spec_*).  Bytes must equal the input; verdicts on damaged and cut streams must be the one-workgroup decoder's
+(which the round-1 tests pin against the reference and the system zlib); the counter says which way a stream went."""
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zlib_amd
+    e = zlib_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def corpus(eng, kind, first, nchunks):
+    import torch
+    src = torch.empty(nchunks * 65536, dtype=torch.uint8, device="cuda")
+    eng.corpus_fill_device(kind, 0x5EED5117, first, nchunks, src.data_ptr())
+    return src.cpu().numpy().tobytes()
+
+
+def raw_deflate(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, mem=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem, strategy)
+    return co.compress(data) + co.flush()
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_system_zlib_streams_are_decoded_in_pieces(eng, kind, level):
+    data = corpus(eng, kind, 100 * level, 256)  # 16 MiB
+    raw = raw_deflate(data, level)
+    before = eng.spec_counts()
+    out = eng.inflate_stream_host(raw, len(data))
+    after = eng.spec_counts()
+    assert out == data
+    assert eng.last_inflate.adler32 == zlib.adler32(data) and eng.last_inflate.crc32 == zlib.crc32(data)
+    assert after[0] == before[0] + 1 and after[1] == before[1], (before, after)
+
+
+def test_streams_of_other_shapes(eng):
+    """Stored blocks (incompressible data), fixed blocks (Z_FIXED), Huffman-only, RLE, small windows, runs of zeros (matches of distance 1
+    across piece borders), a window kept across sync flushes: whatever the finder finds or does not find, the bytes are the input's."""
+    rnd = np.random.default_rng(7).integers(0, 256, 6 << 20, dtype=np.uint8).tobytes()
+    text = corpus(eng, 1, 5, 96)
+    mix = corpus(eng, 0, 9, 96)
+    streams = [
+        ("stored", raw_deflate(rnd, 6), rnd),
+        ("level0", raw_deflate(text, 0), text),
+        ("fixed", raw_deflate(text, 6, zlib.Z_FIXED), text),
+        ("huffman", raw_deflate(mix, 6, zlib.Z_HUFFMAN_ONLY), mix),
+        ("rle", raw_deflate(mix, 6, zlib.Z_RLE), mix),
+        ("window512", raw_deflate(text, 6, wbits=-9), text),
+        ("mem1", raw_deflate(mix, 9, mem=1), mix),
+        ("zeros", raw_deflate(bytes(32 << 20), 6), bytes(32 << 20)),
+        ("mixed", raw_deflate(text[: 2 << 20] + rnd[: 1 << 20] + bytes(1 << 20) + mix[: 2 << 20], 6), text[: 2 << 20] + rnd[: 1 << 20] + bytes(1 << 20) + mix[: 2 << 20]),
+    ]
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    z = b"".join(co.compress(text[i:i + 100000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(text), 100000)) + co.flush()
+    streams.append(("syncflush", z, text))
+    for name, raw, want in streams:
+        out = eng.inflate_stream_host(raw, len(want))
+        assert out == want, name
+        assert eng.last_inflate.crc32 == zlib.crc32(want), name
+
+
+def test_capacity_and_tails(eng):
+    import zlib_amd
+    data = corpus(eng, 0, 33, 128)
+    raw = raw_deflate(data, 6)
+    # a destination that is too small: the size that would have been needed comes back
+    with pytest.raises(zlib_amd.EngineError) as ei:
+        eng.inflate_stream_host(raw, len(data) - 1)
+    assert ei.value.code == -5 and eng.last_inflate.out_bytes == len(data)
+    # a far larger destination than the stream fills
+    assert eng.inflate_stream_host(raw, 64 * len(data)) == data
+    # stream mode: bytes behind the final block stay with the caller
+    from zlib_amd import gpu
+    out = eng.inflate_stream_host(raw + b"TRAILER" * 1000, len(data), flags=1)
+    assert out == data and eng.last_inflate.stream_end == 1 and eng.last_inflate.in_used == len(raw)
+    # strict mode: the same bytes are an error of the body
+    with pytest.raises(zlib_amd.EngineError):
+        eng.inflate_stream_host(raw + b"TRAILER" * 1000, len(data))
+
+
+def test_damaged_and_cut_streams_keep_their_verdicts(eng):
+    import zlib_amd
+    data = corpus(eng, 1, 77, 64)
+    raw = bytearray(raw_deflate(data, 6))
+    for at in (len(raw) // 7, len(raw) // 2, len(raw) - 40000):
+        bad = bytearray(raw)
+        bad[at] ^= 0x10
+        try:
+            want = zlib.decompress(bytes(bad), -15)
+        except zlib.error:
+            want = None
+        if want is None:
+            with pytest.raises(zlib_amd.EngineError) as ei:
+                eng.inflate_stream_host(bytes(bad), len(data) + 65536)
+            assert ei.value.code == -3
+        else:  # the flip landed where the format does not care (a literal, an extra bit): both decode to the same bytes
+            assert eng.inflate_stream_host(bytes(bad), len(want) + 65536) == want
+    cut = bytes(raw[: len(raw) * 2 // 3])
+    with pytest.raises(zlib_amd.EngineError):
+        eng.inflate_stream_host(cut, len(data))
+    out = eng.inflate_stream_host(cut, len(data), flags=1)  # stream mode: not an error, nothing is taken yet
+    assert out == b"" and eng.last_inflate.incomplete == 1 and eng.last_inflate.in_used == 0
+
+
+def test_zlib_api_uncompress_of_a_foreign_stream(eng):
+    from tests import zhost as Z
+    data = corpus(eng, 0, 500, 512)  # 32 MiB
+    z = zlib.compress(data, 6)
+    before = eng.spec_counts()
+    rc, out = Z.uncompress(z, len(data))
+    assert rc == 0 and out == data
+    assert eng.spec_counts()[0] == before[0] + 1

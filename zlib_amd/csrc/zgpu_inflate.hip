@@ -14,6 +14,7 @@
 // match copies (64 bytes per step) and the final store of the chunk (16 bytes per lane).  The whole output chunk
 // (<= 64 KiB) lives in LDS while it is decoded, so back-references never touch global memory.
 #include "zgpu_common.h"
+#include <type_traits>
 #include "../../include/zamd_gpu.h"
 #include <cstdio>
 #include <cstdlib>
@@ -52,8 +53,10 @@ constexpr uint32_t kOutRing = 32768, kOutHalf = kOutRing / 2; // the last 32 KiB
 //   bits 0-3 code length, 4-7 extra bits, 8 literal, 9 end of block, 10 length/distance, 11 invalid symbol, 16-31 byte / base value
 constexpr uint32_t kEntLit = 1u << 8, kEntEob = 1u << 9, kEntLen = 1u << 10, kEntBad = 1u << 11;
 
-struct InflateLds {
-    uint8_t out[kOutRing];
+// RingT: uint8_t, or uint16_t for the speculative decode of a stream's middle (spec_* below): values >= 0x8000 are markers, "the byte
+// at index v & 0x7fff of the 32 KiB in front of this segment", which nobody knows yet
+template <typename RingT, uint32_t kRing = kOutRing> struct InflateLdsT {
+    RingT out[kRing];
     uint32_t ltab[1 << kLBits]; // 0 = code longer than kLBits (or unassigned)
     uint32_t dtab[1 << kDBits];
     uint32_t stage[kStageDwords]; // ring of input dwords
@@ -66,7 +69,13 @@ struct InflateLds {
     uint32_t build_rc, build_n;
     uint32_t end_final, pad1;     // reader -> writer: the segment ended with a final block
 };
+using InflateLds = InflateLdsT<uint8_t>;
+using InflateLdsSpec = InflateLdsT<uint16_t>;
+constexpr uint32_t kScanBytes = 4096; // the block finder reads the input through LDS in pieces of this size (+ the 16 bytes a bit offset at the end reaches into)
+using InflateLdsFind = InflateLdsT<uint8_t, kScanBytes + 64>;
+static_assert(sizeof(InflateLdsFind) <= 12288, "thirteen finder waves per CU");
 static_assert(sizeof(InflateLds) <= 40448, "four waves per CU");
+static_assert(sizeof(InflateLdsSpec) <= 81920, "two workgroups per CU");
 
 // Wave-uniform bit reader over a ring of input dwords in LDS.
 struct BitSrc {
@@ -191,7 +200,7 @@ __device__ inline uint32_t make_entry(uint32_t kind, uint32_t s, uint32_t l)
     return l | (dist_extra(s) << 4) | kEntLen | (dist_base(s) << 16);
 }
 
-__device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
+template <class LDS> __device__ __noinline__ uint32_t build_table(LDS &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
                                              uint16_t *sorted, uint16_t *count, uint32_t lane)
 {
     wave_sync();
@@ -235,7 +244,7 @@ __device__ __noinline__ uint32_t build_table(InflateLds &L, const uint16_t *lens
 // (CodeRows, loaded after build_table); the pattern decodes at the one length whose code range holds its first l bits.
 // Returns symbol | length << 16, or 0xFFFF when the bit pattern is not assigned (incomplete / empty code).
 struct CodeRows { uint32_t first, count, start; };
-__device__ inline CodeRows load_rows(const InflateLds &L, const uint16_t *count, uint32_t lane)
+template <class LDS> __device__ inline CodeRows load_rows(const LDS &L, const uint16_t *count, uint32_t lane)
 {
     CodeRows r;
     r.first = L.work_first[lane & 15]; r.start = L.work_start[lane & 15]; r.count = (lane >= 1 && lane < 16) ? count[lane] : 0u;
@@ -263,6 +272,52 @@ __device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t t
     return e >> 8;
 }
 
+// The header of a dynamic block behind its three type bits (inflate.c:811-880): the counts, the code-length code, the code lengths, the
+// two decoding tables.  Returns 0 or the message of the first rule broken.  Wave-uniform; shared by the reader and the block finder.
+template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b, uint32_t lane, CodeRows &lrows, CodeRows &drows)
+{
+    refill(b, L.stage);
+    const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
+    const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
+    const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
+    if (nlen > 286 || ndist > 30) return kMsgTooMany;
+    wave_sync();
+    for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+    wave_sync();
+    for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
+    wave_sync();
+    // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
+    if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) return kMsgCodeLens;
+    wave_sync();
+    for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+    wave_sync();
+    uint32_t have = 0, prev = 0;
+    while (have < nlen + ndist) {
+        stage_fill(b, L.stage, lane);
+        refill(b, L.stage);
+        const uint32_t s = decode_sym(b, L.dtab, 7);
+        if (s == 0xFFFFu) return kMsgCodeLens;
+        if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
+        uint32_t rep, val = 0;
+        refill(b, L.stage);
+        if (s == 16) { if (have == 0) return kMsgRepeat; val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
+        else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
+        else { rep = 11 + peek(b, 7); drop(b, 7); }
+        if (have + rep > nlen + ndist) return kMsgRepeat;
+        if (lane < rep) L.lens[have + lane] = (uint16_t)val;
+        if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
+        if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
+        prev = val; have += rep;
+    }
+    wave_sync();
+    if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) return kMsgLitLens;
+    lrows = load_rows(L, L.lcount, lane);
+    wave_sync();
+    if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) return kMsgDists;
+    drows = load_rows(L, L.dcount, lane);
+    return kMsgNone;
+}
+
 // One workgroup of two waves per segment.  Wave 0 (the reader) owns the bit stream: block headers, code tables and the
 // token decode; it never needs to know how many bytes came out so far.  Wave 1 (the writer) owns the output: the 32 KiB
 // ring in LDS, match copies, flushes to the destination, and the limits that depend on the output position (distance too
@@ -277,34 +332,59 @@ constexpr uint32_t kWholeStream = 0xFFFFFFFFu; // chunk_size argument: the one s
 
 __device__ inline void block_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
-__global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
-                                                      uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
-                                                      uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
-                                                      const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t stream_mode)
+// SPEC (speculative decode of one stream in pieces, see spec_* below): segment gc starts at BIT offsets[gc] of the input -- a block start
+// the finder believes in -- and ends at the first block boundary at or behind bit offsets[gc + 1], or with the final block; nothing is known about
+// the 32 KiB in front of it, so the ring holds 16-bit symbols (byte, or marker = index into that unknown window) and goes to pages of
+// kOutHalf symbols taken from a pool as it fills, the segment's place in the output being unknown too.
+struct SpecEnd { uint64_t end_bit; uint32_t out_bytes, flags; }; // flags: bit 0 the segment ended with the final block, bit 1 the page pool ran dry
+struct SpecArgs {
+    uint16_t *mid;        // pages of kOutHalf symbols
+    uint64_t *page_owner; // per page: segment << 32 | index of the page within the segment
+    uint32_t *page_count; // pages taken so far
+    uint32_t page_cap;
+    uint16_t *tails;      // per segment: the ring when it ended, oldest symbol first = the last 32 KiB of the segment's output
+    SpecEnd *ends;
+};
+template <bool SPEC>
+__global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
+                                                        uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
+                                                        uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
+                                                        const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t stream_mode, SpecArgs sp)
 {
+    typedef typename std::conditional<SPEC, uint16_t, uint8_t>::type ring_t;
+    typedef InflateLdsT<ring_t> Lds;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    InflateLds &L = *reinterpret_cast<InflateLds *>(lds_raw);
+    Lds &L = *reinterpret_cast<Lds *>(lds_raw);
     const uint32_t c = blockIdx.x, lane = threadIdx.x & 63u;
     const uint32_t role = uni(threadIdx.x >> 6); // 0 reader, 1 writer
     if (c >= nchunks) return;
     const uint64_t gc = chunk0 + c;
     uint64_t seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
-    // the table may arrive next to the data from anywhere: an entry that does not lie inside the input, runs backwards or is longer than
-    // a 32-bit bit count can express is an error of that segment, decoded as an empty one (nothing outside the input is ever read)
-    const bool bad_table = seg_lo > seg_hi || seg_hi > in_bytes || seg_hi - seg_lo >= (1ull << 29);
+    uint32_t bit_lead = 0, stop_bits = 0xFFFFFFFFu; // SPEC: bits of the first byte in front of the start; where the next segment starts, in bits from seg_lo
+    bool bad_table;
+    if (SPEC) {
+        const uint64_t s0 = seg_lo, s1 = seg_hi;
+        bad_table = s0 >= s1 || s1 > in_bytes * 8 || s1 - (s0 & ~7ull) >= (1ull << 31);
+        seg_lo = s0 >> 3; seg_hi = in_bytes - seg_lo < (1ull << 28) ? in_bytes : seg_lo + (1ull << 28);
+        bit_lead = (uint32_t)(s0 & 7u); stop_bits = bad_table ? 0u : (uint32_t)(s1 - seg_lo * 8);
+    } else {
+        // the table may arrive next to the data from anywhere: an entry that does not lie inside the input, runs backwards or is longer than
+        // a 32-bit bit count can express is an error of that segment, decoded as an empty one (nothing outside the input is ever read)
+        bad_table = seg_lo > seg_hi || seg_hi > in_bytes || seg_hi - seg_lo >= (1ull << 29);
+    }
     if (bad_table) { seg_lo = 0; seg_hi = 0; }
-    const bool must_be_final = gc == last_chunk;
+    const bool must_be_final = !SPEC && gc == last_chunk;
     // chunk_size_arg == 0: "compact" mode, segments of any size up to 64 KiB are decoded into per-chunk slots and
     // concatenated afterwards (used for streams whose chunks are not all full, e.g. flushed mid-chunk)
     const bool compact = chunk_size_arg == 0;
     // chunk_size_arg == kWholeStream: one segment of any size (a stream that was not produced in chunks): decoded from end to
     // end by this one workgroup straight into the destination, limited only by the destination's capacity (a destination
     // that is too small still gets the size that would have been needed)
-    const bool whole = chunk_size_arg == kWholeStream;
+    const bool whole = SPEC || chunk_size_arg == kWholeStream;
     const uint32_t chunk_size = compact ? kChunkMax : whole ? 0xFFFF0000u : chunk_size_arg;
     // a preset dictionary (inflateSetDictionary, inflate.c:1200-1236) is what the window holds before the first byte: in the ring it
     // sits right below position 0, and the first segment may reach that much farther back
-    const uint32_t reach = (gc == 0) ? dict_len : 0u;
+    const uint32_t reach = (gc == 0) ? dict_len : SPEC ? kOutRing : 0u;
     if (threadIdx.x == 0) { L.abort_flag = 0; L.end_bits = 0; L.end_final = 0; }
     INF_T0();
 
@@ -362,6 +442,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
         prime(b, L.stage);
         refill(b, L.stage); refill(b, L.stage);
         drop(b, lead * 8);
+        if (SPEC) drop(b, bit_lead);
         auto reposition = [&](uint32_t pos) { // the scalar reader at bit `pos` of the staged dwords
             b.rd = pos >> 5; b.hold = 0; b.bits = 0;
             prime(b, L.stage); refill(b, L.stage); refill(b, L.stage);
@@ -373,6 +454,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
         INF_T(0);
         while (!err && !last && !stop) {
             if (consumed_bits(b) >= b.seg_bits) break; // segment exhausted at a block boundary (normal end of a non-final segment)
+            if (SPEC && org_bits + consumed_bits(b) - lead * 8 >= stop_bits) break; // a block boundary at or behind the next segment's start
             stage_fill(b, L.stage, lane); wave_sync();
             refill(b, L.stage);
             const uint32_t hdr = peek(b, 3); drop(b, 3);
@@ -414,46 +496,8 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                 build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
                 drows = load_rows(L, L.dcount, lane);
             } else {
-                refill(b, L.stage);
-                const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
-                const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
-                const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
-                if (nlen > 286 || ndist > 30) { err = kMsgTooMany; break; }
-                wave_sync();
-                for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-                wave_sync();
-                for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
-                wave_sync();
-                // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
-                if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgCodeLens; break; }
-                wave_sync();
-                for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-                wave_sync();
-                uint32_t have = 0, prev = 0;
-                while (have < nlen + ndist) {
-                    stage_fill(b, L.stage, lane);
-                    refill(b, L.stage);
-                    const uint32_t s = decode_sym(b, L.dtab, 7);
-                    if (s == 0xFFFFu) { err = kMsgCodeLens; break; }
-                    if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
-                    uint32_t rep, val = 0;
-                    refill(b, L.stage);
-                    if (s == 16) { if (have == 0) { err = kMsgRepeat; break; } val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
-                    else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
-                    else { rep = 11 + peek(b, 7); drop(b, 7); }
-                    if (have + rep > nlen + ndist) { err = kMsgRepeat; break; }
-                    if (lane < rep) L.lens[have + lane] = (uint16_t)val;
-                    if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
-                    if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
-                    prev = val; have += rep;
-                }
+                err = dynamic_header(L, b, lane, lrows, drows);
                 if (err) break;
-                wave_sync();
-                if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) { err = kMsgLitLens; break; }
-                lrows = load_rows(L, L.lcount, lane);
-                wave_sync();
-                if (build_table(L, L.lens + nlen, ndist, 2, kDBits, L.dtab, L.dsym, L.dcount, lane)) { err = kMsgDists; break; }
-                drows = load_rows(L, L.dcount, lane);
             }
             wave_sync();
             INF_T(1);
@@ -574,6 +618,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
         if (!err && !stop) {
             const uint32_t used = consumed_bits(b);
             if (used > b.seg_bits) err = kMsgTruncated;                       // decoded past the end of the segment
+            else if (SPEC) { if (!seen_final && org_bits + used - lead * 8 < stop_bits) err = kMsgTruncated; } // the input ended first
             else if (must_be_final && !seen_final) err = kMsgTruncated;       // the stream never ends
             else if (stream_mode && seen_final) { }                           // stream mode: the stream ends where its final block ends, whatever follows
             else if (!must_be_final && seen_final) err = kMsgTrailing;        // a final block before the last segment
@@ -593,22 +638,26 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
     // =========================================== writer ===========================================
     uint32_t err = kMsgNone;
     uint32_t o = 0;       // bytes produced
+    if (SPEC) {
+        for (uint32_t i = lane; i < kOutRing; i += 64) L.out[i] = (ring_t)(0x8000u | i); // slot i, never written, is byte i of the window in front
+        if (gc == 0) for (uint32_t i = lane; i < dict_len; i += 64) L.out[(kOutRing - dict_len + i) & (kOutRing - 1)] = dict[i];
+    } else
     for (uint32_t i = lane; i < reach; i += 64) L.out[(kOutRing - reach + i) & (kOutRing - 1)] = dict[i];
     uint32_t flushed = 0; // bytes already copied from the LDS ring to the destination (a multiple of kOutHalf until the end)
     bool nofit = false;   // direct placement: the destination ended before the chunk did
     uint8_t *dst = compact ? out + (uint64_t)c * kChunkMax : whole ? out : out + gc * (uint64_t)chunk_size;
-    const uint64_t dst_room = compact ? kChunkMax : whole ? out_cap : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
+    const uint64_t dst_room = SPEC ? ~0ull : compact ? kChunkMax : whole ? out_cap : (out_cap > gc * (uint64_t)chunk_size ? out_cap - gc * (uint64_t)chunk_size : 0);
     // copy a match of `len` bytes at distance `dist` to output position `at`; a distance shorter than the length repeats its
     // pattern (byte-sequential semantics of inffast.c:246-259).  The ring holds the last 32 KiB: a read at the full distance
     // 32768 hits the slot its own lane is about to write.
     auto copy_match = [&](uint32_t at, uint32_t len, uint32_t dist) {
         __builtin_amdgcn_wave_barrier();
         if (len <= 64 && dist >= len) { // the common case
-            if (lane < len) { const uint8_t v = L.out[(at - dist + lane) & (kOutRing - 1)]; L.out[(at + lane) & (kOutRing - 1)] = v; }
+            if (lane < len) { const ring_t v = L.out[(at - dist + lane) & (kOutRing - 1)]; L.out[(at + lane) & (kOutRing - 1)] = v; }
         } else if (dist >= len || dist >= 64) {
             for (uint32_t i0 = 0; i0 < len; i0 += (dist < 64 ? dist : 64)) {
                 const uint32_t span = dist < 64 ? dist : 64, i = i0 + lane;
-                uint8_t v = 0;
+                ring_t v = 0;
                 if (lane < span && i < len) v = L.out[(at - dist + i) & (kOutRing - 1)];
                 if (lane < span && i < len) L.out[(at + i) & (kOutRing - 1)] = v;
                 __builtin_amdgcn_wave_barrier();
@@ -627,8 +676,22 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
         INF_T(11);
         wave_sync();
         uint32_t nbytes = upto - flushed;
+        if (SPEC) { // the next page of the pool (flushed is a multiple of kOutHalf: the page's index within the segment)
+            uint32_t page = 0;
+            if (lane == 0) page = atomicAdd(sp.page_count, 1u);
+            page = uni(page);
+            if (page >= sp.page_cap) nofit = true;
+            else {
+                if (lane == 0) sp.page_owner[page] = (gc << 32) | (flushed / kOutHalf);
+                const uint4 *s128 = reinterpret_cast<const uint4 *>(L.out + (flushed & (kOutRing - 1)));
+                uint4 *d128 = reinterpret_cast<uint4 *>(sp.mid + (uint64_t)page * kOutHalf);
+                for (uint32_t i = lane; i < (nbytes + 7) / 8; i += 64) d128[i] = s128[i]; // (whole vectors: the page and the ring half have the room)
+            }
+            flushed = upto;
+            return;
+        }
         if ((uint64_t)flushed + nbytes > dst_room) { nofit = true; nbytes = dst_room > flushed ? (uint32_t)(dst_room - flushed) : 0; }
-        const uint8_t *src_r = L.out + (flushed & (kOutRing - 1));
+        const uint8_t *src_r = reinterpret_cast<const uint8_t *>(L.out) + (flushed & (kOutRing - 1)); // (the byte ring; SPEC has returned above)
         uint8_t *d = dst + flushed;
         if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
             const uint4 *s128 = reinterpret_cast<const uint4 *>(src_r);
@@ -675,7 +738,7 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
                         take &= (2ull << (uint32_t)__builtin_ctzll(hz)) - 1; rest = todo & ~take;
                         pend = rest ? (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)__builtin_ctzll(rest)) : o_end;
                     }
-                    if (sel_mask(take, k2, 0u) == 1) L.out[offv & (kOutRing - 1)] = (uint8_t)(tw >> 2);
+                    if (sel_mask(take, k2, 0u) == 1) L.out[offv & (kOutRing - 1)] = (ring_t)(uint8_t)(tw >> 2);
                     INF_T(10);
                     uint64_t mm = take & __ballot(k2 == 2);
                     while (mm) {
@@ -713,18 +776,21 @@ __global__ void __launch_bounds__(128) inflate_kernel(const uint8_t *__restrict_
         if (err && lane == 0) L.abort_flag = 1; // void output: the reader stops at its next hand-over and sends its end command
     }
     if (!err) err = reader_err;
-    if (!err && !compact && !must_be_final && o != chunk_size) err = kMsgShort; // direct placement assumes full chunks
+    if (!err && !compact && !SPEC && !must_be_final && o != chunk_size) err = kMsgShort; // direct placement assumes full chunks
 #ifdef ZGPU_INF_DEBUG2
     if (err && lane == 0) printf("chunk %u err %u o %u\n", c, err, o);
 #endif
     // the rest of the chunk (an error leaves what was flushed before it was found; the status says the chunk is void)
-    if (!err) flush_to(o);
+    if (!err && (!SPEC || o != flushed)) flush_to(o);
+    if (SPEC && !err) // the ring is the last 32 KiB of what this segment knows: slots it never wrote still name the window in front
+        for (uint32_t j = lane; j < kOutRing; j += 64) sp.tails[gc * kOutRing + j] = L.out[(o + j) & (kOutRing - 1)];
     const bool fits = !nofit;
     INF_T(4);
     if (lane == 0) {
         status[c].code = err ? ZGPU_DATA_ERROR : (fits ? ZGPU_OK : ZGPU_BUF_ERROR);
         status[c].msg = err; status[c].out_bytes = err ? 0 : o;
         status[c].used = err ? 0u : (((L.end_bits + 7u) >> 3) | (L.end_final << 31));
+        if (SPEC) { sp.ends[gc].end_bit = seg_lo * 8 + L.end_bits; sp.ends[gc].out_bytes = err ? 0 : o; sp.ends[gc].flags = err ? (err << 8) : (L.end_final | (nofit ? 2u : 0u)); }
 #ifdef ZGPU_INF_TIME
         t_acc[6] = n_mat;
         for (int i_ = 0; i_ < 16; i_++) if (t_acc[i_]) atomicAdd(&inf_time[i_], t_acc[i_]);
@@ -802,6 +868,34 @@ hipStream_t engine_copy_stream(zgpu_engine *e);
 hipEvent_t engine_copy_event(zgpu_engine *e, size_t i);
 struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
+// Adler-32 and CRC-32 of the produced bytes (same kernels as the compress side), over 64 KiB pieces of the output
+static int output_checksums(zgpu_engine *e, const uint8_t *d_out, uint64_t nbytes, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
+{
+    const uint64_t max_pieces = (out_cap >> 16) + 2;
+    const uint32_t cbatch_cap = (uint32_t)(max_pieces < 65536 ? max_pieces : 65536);
+    const uint64_t npieces = nbytes ? (nbytes + kChunkMax - 1) / kChunkMax : 1;
+    const uint32_t cbatch = (uint32_t)(npieces < cbatch_cap ? npieces : cbatch_cap);
+    ChunkMeta *meta = engine_meta(e, cbatch);
+    uint64_t *oscr = engine_offsets_scratch(e, npieces + 2);
+    if (!meta || !oscr) return engine_fail(e, ZGPU_MEM_ERROR, "checksum scratch");
+    RunStateHostI rs{}; rs.adler_a = 1;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    for (uint64_t c0 = 0; c0 < npieces; c0 += cbatch) {
+        const uint32_t nb = (uint32_t)(npieces - c0 < cbatch ? npieces - c0 : cbatch);
+        ChunkGeom g{}; g.in = d_out; g.in_bytes = nbytes; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
+        ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
+        launch_adler(g, meta, st);
+        launch_crc(g, meta, st);
+        launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st, true);
+    }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, engine_run_state(e), sizeof rs, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    engine_collect(e);
+    res->adler32 = rs.adler_a | (rs.adler_b << 16);
+    res->crc32 = rs.crc;
+    return ZGPU_OK;
+}
+
 // stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used);
 // open_end: the last segment ends with a flush marker like the others, no segment has to hold the final block
 // h_dst (direct placement only): the caller's host buffer; every batch's output is copied there on the engine's copy stream while the
@@ -837,15 +931,16 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
     static bool opt_in = false;
-    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds)); opt_in = true; }
+    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds)); opt_in = true; }
     hipEvent_t ev{};
+    int rc_sum = 0;
     prof_span_begin(e, st, &ev);
     uint64_t *oscr = engine_offsets_scratch(e, nchunks + 1 + (out_cap >> 16) + 2);
     if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
-        hipLaunchKernelGGL(inflate_kernel, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
-                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), stream_mode);
+        hipLaunchKernelGGL(inflate_kernel_t<false>, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
+                           compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), stream_mode, SpecArgs{});
         hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc, stream_mode, last_chunk, compact ? meta : nullptr, (uint32_t)kMsgTruncated);
         if (compact) {
             launch_scan(meta, nb, c0, oscr, engine_run_state(e), out_cap, st); // out_bytes -> byte offsets, continuing across batches
@@ -880,24 +975,8 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     res->out_bytes = h[0]; res->first_bad_chunk = h[1] ? (int32_t)(h[1] - 1) : -1; res->error_code = (int32_t)(int64_t)h[2]; res->error_msg = (uint32_t)h[3];
     if (h[1]) { engine_collect(e); return engine_fail(e, res->error_code, kInfMessages[res->error_msg < kMsgCount ? res->error_msg : 0]); }
     if (h[0] > out_cap) { engine_collect(e); return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small"); }
-    // Adler-32 of the produced bytes (same kernels as the compress side), over 64 KiB pieces of the output
-    const uint64_t npieces = h[0] ? (h[0] + kChunkMax - 1) / kChunkMax : 1;
-    rs = RunStateHostI{}; rs.adler_a = 1;
-    ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    const uint32_t cbatch = (uint32_t)(npieces < cbatch_cap ? npieces : cbatch_cap);
-    for (uint64_t c0 = 0; c0 < npieces; c0 += cbatch) {
-        const uint32_t nb = (uint32_t)(npieces - c0 < cbatch ? npieces - c0 : cbatch);
-        ChunkGeom g{}; g.in = d_out; g.in_bytes = h[0]; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
-        ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
-        launch_adler(g, meta, st);
-        launch_crc(g, meta, st);
-        launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st, true);
-    }
-    ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, engine_run_state(e), sizeof rs, hipMemcpyDeviceToHost, st));
-    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
-    engine_collect(e);
-    res->adler32 = rs.adler_a | (rs.adler_b << 16);
-    res->crc32 = rs.crc;
+    rc_sum = output_checksums(e, d_out, h[0], out_cap, res, st);
+    if (rc_sum) return rc_sum;
     if (h_dst && !to_host && h[0]) { // a host destination that was not served batch by batch
         ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst, d_out, h[0], hipMemcpyDeviceToHost, st));
         ZGPU_HIP_CHECK(hipStreamSynchronize(st));
@@ -925,7 +1004,311 @@ hipStream_t engine_stream(zgpu_engine *e);
 } // namespace zgpu
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
+static std::atomic<uint64_t> g_spec_done{0}, g_whole_done{0};
+namespace zgpu {
+// ======================================================================================================================================
+// A stream that was not produced in chunks (any other zlib's output), decoded in pieces all the same.
+//   1. spec_find_kernel: behind every `spacing` bytes of the input, the first bit offset that reads as the header of a dynamic block the
+//      decoder would accept (type bits, counts in range, a complete code-length code -- checked by every lane for its own offset --, then
+//      the code lengths and the two codes through the decoder's own dynamic_header()).  Such a header at a wrong offset is possible
+//      but rare; step 3 finds out.
+//   2. inflate_kernel_t<true>: one workgroup per piece, from its start to the first block boundary at or behind the next piece's start,
+//      into 16-bit symbols: a byte, or a marker for "byte j of the 32 KiB in front of this piece".
+//   3. the host checks the chain: every piece must have ended exactly where the next one started, the last with the final block.  Anything
+//      else (a false start, damaged data, input that stops early) and the stream goes to the one-workgroup decoder, whose verdicts stand.
+//   4. spec_window_kernel: piece by piece, the last 32 KiB of output with the markers replaced (the only serial step: 32 K look-ups each);
+//      spec_resolve_kernel: every page of symbols to its place in the output, markers looked up in the window of the piece in front.
+// ======================================================================================================================================
+__global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint64_t spacing, uint32_t ntargets, uint64_t *found)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    InflateLdsFind &L = *reinterpret_cast<InflateLdsFind *>(lds_raw);
+    const uint32_t t = blockIdx.x + 1, lane = threadIdx.x;
+    if (t > ntargets) return;
+    const uint64_t total_bits = in_bytes * 8, lo_bit = (uint64_t)t * spacing * 8;
+    const uint64_t hi_bit = (uint64_t)(t + 1) * spacing * 8 < total_bits ? (uint64_t)(t + 1) * spacing * 8 : total_bits;
+    const uint32_t *g32 = reinterpret_cast<const uint32_t *>(in); // (the input buffer is a device allocation: aligned)
+    const uint64_t gdwords = (in_bytes + 3) >> 2;
+    uint64_t result = ~0ull;
+    // the bytes to scan come through LDS, kScanBytes at a time
+    uint32_t *scan = reinterpret_cast<uint32_t *>(L.out);
+    const uint4 *g128 = reinterpret_cast<const uint4 *>(in);
+    const uint64_t gvecs = (in_bytes + 15) >> 4; // (the allocation behind `in` is padded: engine_ensure_stage)
+    for (uint64_t blk = lo_bit; blk < hi_bit && result == ~0ull; blk += kScanBytes * 8) {
+        wave_sync();
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBytes / 16 / 64 + 1; k++) {
+            const uint32_t v = k * 64 + lane;
+            const uint64_t gv = (blk >> 7) + v;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (v <= kScanBytes / 16 && gv < gvecs) q = g128[gv];
+            if (v <= kScanBytes / 16) reinterpret_cast<uint4 *>(scan)[v] = q;
+        }
+        wave_sync();
+        const uint64_t blk_hi = blk + kScanBytes * 8 < hi_bit ? blk + kScanBytes * 8 : hi_bit;
+    for (uint64_t base = blk; base < blk_hi && result == ~0ull; base += 64) {
+        const uint64_t p = base + lane;
+        const uint32_t rel = (uint32_t)(p - blk), wi = rel >> 5, sh = rel & 31u;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = scan[wi + k];
+        const uint32_t b0 = __builtin_amdgcn_alignbit(w[1], w[0], sh), b1 = __builtin_amdgcn_alignbit(w[2], w[1], sh), b2 = __builtin_amdgcn_alignbit(w[3], w[2], sh);
+        // BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29, HCLEN; the code-length code complete (inftrees.c:106-138: sum of 2^-len == 1)
+        const uint32_t nlen = (b0 >> 3) & 31u, ndist = (b0 >> 8) & 31u, ncode = ((b0 >> 13) & 15u) + 4;
+        uint64_t y = ((((uint64_t)b1 << 32) | b0) >> 17) | ((uint64_t)b2 << 47);
+        y &= (1ull << (3 * ncode)) - 1; // lengths that are not sent are 0
+        const uint32_t ylo = (uint32_t)y, ymid = (uint32_t)(y >> 30);
+        uint32_t kraft = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 10; i++) kraft += (128u >> ((ylo >> (3 * i)) & 7u)) & 127u;  // a length of 0 counts nothing
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) kraft += (128u >> ((ymid >> (3 * i)) & 7u)) & 127u;
+        const bool ok = p + 17 + 3 * ncode < hi_bit && (b0 & 7u) == 4u && nlen <= 29 && ndist <= 29 && kraft == 128;
+        uint64_t m = __ballot(ok);
+        while (m) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
+            const uint64_t cand = base + l;
+            BitSrc b;
+            b.g32 = g32; b.gdwords = gdwords; b.d0 = cand >> 5; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+            const uint64_t left = total_bits - (cand & ~31ull);
+            b.seg_bits = left > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)left;
+            wave_sync();
+            stage_fill(b, L.stage, lane);
+            wave_sync();
+            prime(b, L.stage);
+            refill(b, L.stage); refill(b, L.stage);
+            drop(b, (uint32_t)cand & 31u);
+            drop(b, 3);
+            CodeRows lr{}, dr{};
+            const uint32_t err = dynamic_header(L, b, lane, lr, dr);
+            wave_sync();
+            // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
+            if (!err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits) { result = cand; break; }
+        }
+    }
+    }
+    if (lane == 0) found[t - 1] = result;
+}
+
+// Piece by piece: window[i] = the last 32 KiB of the output up to the end of piece i, from the piece's tail (symbols) and window[i - 1].
+// out_start[i] = where piece i begins in the output.  flag[0] != 0: a marker named a byte in front of the stream's first (the stream is damaged
+// or a start was false: the caller falls back).  One workgroup; the windows alternate between two LDS buffers.
+__global__ void __launch_bounds__(1024) spec_window_kernel(const uint16_t *__restrict__ tails, const SpecEnd *__restrict__ ends, uint32_t nseg, uint32_t dict_len,
+                                                           uint8_t *__restrict__ windows, uint64_t *__restrict__ out_start, uint32_t *flag)
+{
+    __shared__ uint8_t win[2][kOutRing];
+    const uint32_t tid = threadIdx.x;
+    uint64_t pos = 0; // output bytes in front of piece i
+    uint32_t bad = 0;
+    constexpr uint32_t kPer = kOutRing / 8 / 1024; // vectors of 8 symbols per thread
+    uint4 nxt[kPer];
+    uint32_t nxt_out = nseg ? ends[0].out_bytes : 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < kPer; r++) nxt[r] = nseg ? reinterpret_cast<const uint4 *>(tails)[r * 1024 + tid] : make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 0; i < nseg; i++) {
+        const uint8_t *prev = win[(i + 1) & 1];
+        uint8_t *cur = win[i & 1];
+        uint4 q4[kPer];
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; r++) q4[r] = nxt[r];
+        const uint32_t out_i = nxt_out;
+        if (i + 1 < nseg) { // the next piece's tail is on its way while this one is resolved (the chain is as long as the stream has pieces)
+            const uint4 *t4n = reinterpret_cast<const uint4 *>(tails + (uint64_t)(i + 1) * kOutRing);
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; r++) nxt[r] = t4n[r * 1024 + tid];
+            nxt_out = ends[i + 1].out_bytes;
+        }
+        // bytes of the previous window that exist: index >= kOutRing - (pos + dict_len) (piece 0 holds its dictionary itself)
+        const uint64_t have_prev = i == 0 ? 0 : pos + dict_len, end = pos + out_i, have_cur = end + dict_len;
+        const uint32_t vf_prev = have_prev >= kOutRing ? 0u : kOutRing - (uint32_t)have_prev, vf_cur = have_cur >= kOutRing ? 0u : kOutRing - (uint32_t)have_cur;
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; r++) {
+            const uint32_t v = r * 1024 + tid;
+            const uint4 q = q4[r];
+            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+            uint32_t o8[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t sym = (ws[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, j = v * 8 + k;
+                uint32_t byte = sym & 255u;
+                if (sym & 0x8000u) {
+                    const uint32_t idx = sym & 0x7FFFu;
+                    if (idx >= vf_prev) byte = prev[idx];
+                    else { byte = 0; if (j >= vf_cur) bad = 1; } // a produced byte copied from in front of the stream
+                }
+                o8[k >> 2] |= byte << ((k & 3) * 8);
+            }
+            reinterpret_cast<uint2 *>(cur)[v] = make_uint2(o8[0], o8[1]);
+            reinterpret_cast<uint2 *>(windows + (uint64_t)i * kOutRing)[v] = make_uint2(o8[0], o8[1]);
+        }
+        if (tid == 0) out_start[i] = pos;
+        pos = end;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the window in LDS; __syncthreads would wait for the next tail's loads as well)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (tid == 0) out_start[nseg] = pos;
+    if (bad) atomicOr(flag, 1u);
+}
+
+// One workgroup per page of symbols: to its place in the output, markers through the window of the piece in front.
+__global__ void __launch_bounds__(256) spec_resolve_kernel(const uint16_t *__restrict__ mid, const uint64_t *__restrict__ page_owner, uint32_t npages, const SpecEnd *__restrict__ ends,
+                                                           uint32_t nseg, const uint8_t *__restrict__ windows, const uint64_t *__restrict__ out_start, uint32_t dict_len,
+                                                           uint8_t *__restrict__ out, uint64_t out_cap, uint32_t *flag)
+{
+    const uint32_t pg = blockIdx.x;
+    if (pg >= npages) return;
+    const uint64_t ow = page_owner[pg];
+    const uint32_t seg = (uint32_t)(ow >> 32), k = (uint32_t)ow;
+    if (seg >= nseg) return; // a piece behind the end of the stream
+    const uint32_t len = ends[seg].out_bytes, from = k * kOutHalf;
+    if (from >= len) return;
+    const uint32_t n = len - from < kOutHalf ? len - from : kOutHalf;
+    const uint64_t at = out_start[seg] + from;
+    const uint64_t have_prev = seg == 0 ? 0 : out_start[seg] + dict_len;
+    const uint32_t vf_prev = have_prev >= kOutRing ? 0u : kOutRing - (uint32_t)have_prev;
+    const uint8_t *win = seg ? windows + (uint64_t)(seg - 1) * kOutRing : windows;
+    const uint16_t *src = mid + (uint64_t)pg * kOutHalf;
+    uint32_t bad = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t sym = src[i];
+        uint32_t byte = sym & 255u;
+        if (sym & 0x8000u) {
+            const uint32_t idx = sym & 0x7FFFu;
+            if (seg != 0 && idx >= vf_prev) byte = win[idx]; else { byte = 0; bad = 1; }
+        }
+        if (at + i < out_cap) out[at + i] = (uint8_t)byte;
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
+// 0: decoded (res complete); 1: not this way (the caller uses the one-workgroup decoder); anything else: an error of the engine
+static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st,
+                            uint32_t stream_mode)
+{
+    static long min_bytes = -1;
+    if (min_bytes < 0) { const char *v = getenv("ZGPU_SPEC_MIN_BYTES"); min_bytes = v ? atol(v) : 128 * 1024; }
+    if ((long)in_bytes < min_bytes || in_bytes >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return 1;
+    res->adler32 = 1; res->crc32 = 0; res->in_used = in_bytes; res->stream_end = 0; res->incomplete = 0;
+    uint64_t spacing = (in_bytes / 4096 + 4095) & ~4095ull;
+    if (spacing < 32768) spacing = 32768;
+    // the finders stand four times as close as the pieces will be (each scans to the next finder at most; of what they find the host keeps starts
+    // at least three quarters of `spacing` apart)
+    const uint64_t fspacing = spacing / 4 < 16384 ? 16384 : (spacing / 4 + 4095) & ~4095ull;
+    const uint32_t ntargets = (uint32_t)((in_bytes - 1) / fspacing);
+    if (ntargets < 3) return 1;
+    uint64_t *d_found = static_cast<uint64_t *>(engine_scratch(e, (size_t)ntargets * 8 + 64));
+    if (!d_found) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
+    static bool opt_in = false;
+    if (!opt_in) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsSpec));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(spec_find_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsFind));
+        opt_in = true;
+    }
+    hipEvent_t ev{};
+    prof_span_begin(e, st, &ev);
+    hipLaunchKernelGGL(spec_find_kernel, dim3(ntargets), dim3(64), sizeof(InflateLdsFind), st, d_in, in_bytes, fspacing, ntargets, d_found);
+    std::vector<uint64_t> starts(ntargets + 2);
+    ZGPU_HIP_CHECK(hipMemcpyAsync(starts.data() + 1, d_found, (size_t)ntargets * 8, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    starts[0] = 0;
+    size_t n = 1;
+    for (uint32_t i = 1; i <= ntargets; i++) if (starts[i] != ~0ull && starts[i] >= starts[n - 1] + spacing * 6 && starts[i] + spacing * 2 < in_bytes * 8) starts[n++] = starts[i];
+    starts[n] = in_bytes * 8;
+    const uint32_t nseg = (uint32_t)n;
+    static const bool dbg = getenv("ZGPU_SPEC_DEBUG") != nullptr;
+    if (dbg) {
+        fprintf(stderr, "[spec] %llu bytes, spacing %llu, %u targets, %u pieces; first starts:", (unsigned long long)in_bytes, (unsigned long long)spacing, ntargets, nseg);
+        for (uint32_t i = 0; i < nseg && i < 6; i++) fprintf(stderr, " %llu", (unsigned long long)starts[i]);
+        fprintf(stderr, "\n");
+    }
+    if (nseg < 3) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+    // pages: what the output can hold, or -- when the caller's buffer is far larger than this stream can fill -- eight times the input first
+    uint64_t guess = in_bytes * 8 + (16u << 20);
+    for (int attempt = 0;; attempt++) {
+        const uint64_t room = out_cap < guess ? out_cap : guess;
+        const uint64_t pages64 = room / kOutHalf + nseg + 2;
+        if (pages64 >= 0xFFFFFFFFull) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+        const uint32_t page_cap = (uint32_t)pages64;
+        // one allocation: starts | ends | out_start | status | counters | page owners | windows | tails | pages
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_starts = carve((size_t)(nseg + 1) * 8), o_ends = carve((size_t)nseg * sizeof(SpecEnd)), o_ostart = carve((size_t)(nseg + 1) * 8),
+                     o_status = carve((size_t)nseg * sizeof(InfStatus)), o_cnt = carve(64), o_owner = carve((size_t)page_cap * 8),
+                     o_win = carve((size_t)nseg * kOutRing), o_tails = carve((size_t)nseg * kOutRing * 2), o_mid = carve((size_t)page_cap * kOutHalf * 2);
+        uint8_t *base = static_cast<uint8_t *>(engine_scratch2(e, off));
+        if (!base) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; } // (no room for the symbols: the slow way needs none)
+        uint64_t *d_starts = reinterpret_cast<uint64_t *>(base + o_starts), *d_ostart = reinterpret_cast<uint64_t *>(base + o_ostart);
+        SpecEnd *d_ends = reinterpret_cast<SpecEnd *>(base + o_ends);
+        uint32_t *d_cnt = reinterpret_cast<uint32_t *>(base + o_cnt);
+        SpecArgs sp{};
+        sp.mid = reinterpret_cast<uint16_t *>(base + o_mid); sp.page_owner = reinterpret_cast<uint64_t *>(base + o_owner); sp.page_count = d_cnt; sp.page_cap = page_cap;
+        sp.tails = reinterpret_cast<uint16_t *>(base + o_tails); sp.ends = d_ends;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 64, st));
+        ZGPU_HIP_CHECK(hipMemsetAsync(d_ends, 0xFF, (size_t)nseg * sizeof(SpecEnd), st));
+        hipLaunchKernelGGL(inflate_kernel_t<true>, dim3(nseg), dim3(128), sizeof(InflateLdsSpec), st, d_in, in_bytes, d_starts, 0ull, nseg, ~0ull, kWholeStream,
+                           d_out, out_cap, reinterpret_cast<InfStatus *>(base + o_status), nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), 1u, sp);
+        ZGPU_HIP_CHECK(hipGetLastError());
+        std::vector<SpecEnd> ends(nseg);
+        uint32_t cnt[2] = {0, 0};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(ends.data(), d_ends, (size_t)nseg * sizeof(SpecEnd), hipMemcpyDeviceToHost, st));
+        ZGPU_HIP_CHECK(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        // the chain
+        uint32_t used_seg = 0; uint64_t total = 0; bool ended = false, dry = false;
+        for (uint32_t i = 0; i < nseg; i++) {
+            if (ends[i].flags >> 8) break;               // an error (or never written)
+            total += ends[i].out_bytes; used_seg = i + 1; dry = dry || (ends[i].flags & 2u);
+            if (ends[i].flags & 1u) { ended = true; break; }
+            if (i + 1 == nseg || ends[i].end_bit != starts[i + 1]) break;
+        }
+        const uint64_t end_byte = ended ? (ends[used_seg - 1].end_bit + 7) >> 3 : 0;
+        if (dbg) {
+            fprintf(stderr, "[spec] chain: %u of %u pieces, ended %d, total %llu, pages %u of %u, dry %d\n", used_seg, nseg, (int)ended, (unsigned long long)total, cnt[0], page_cap, (int)dry);
+            for (uint32_t i = used_seg ? used_seg - 1 : 0; i < nseg && i < used_seg + 2; i++)
+                fprintf(stderr, "[spec]   piece %u: start %llu end %llu next %llu out %u flags %#x\n", i, (unsigned long long)starts[i], (unsigned long long)ends[i].end_bit,
+                        (unsigned long long)starts[i + 1], ends[i].out_bytes, ends[i].flags);
+        }
+        if (!ended && stream_mode && used_seg + 1 == nseg && (ends[nseg - 1].flags >> 8) == kMsgTruncated && ends[used_seg - 1].end_bit == starts[used_seg]) {
+            // every piece chained and the last one ran out of input inside a block: the stream is not all there yet (one workgroup would say the same)
+            prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
+            engine_collect(e);
+            res->incomplete = 1; res->in_used = 0; res->out_bytes = 0; res->stream_end = 0; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0;
+            return ZGPU_OK;
+        }
+        if (!ended || (!stream_mode && end_byte != in_bytes)) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+        if (total > out_cap) {
+            prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
+            res->out_bytes = total; res->first_bad_chunk = -1; res->error_code = ZGPU_BUF_ERROR; res->error_msg = 0;
+            engine_collect(e);
+            return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+        }
+        if (dry) { // the pool was sized from the guess: now the size is known
+            if (attempt) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+            guess = total + kOutHalf;
+            continue;
+        }
+        const uint32_t npages = cnt[0] < page_cap ? cnt[0] : page_cap;
+        hipLaunchKernelGGL(spec_window_kernel, dim3(1), dim3(1024), 0, st, sp.tails, d_ends, used_seg, engine_inflate_dict_len(e), base + o_win, d_ostart, d_cnt + 4);
+        if (npages) hipLaunchKernelGGL(spec_resolve_kernel, dim3(npages), dim3(256), 0, st, sp.mid, sp.page_owner, npages, d_ends, used_seg, base + o_win, d_ostart,
+                                       engine_inflate_dict_len(e), d_out, out_cap, d_cnt + 4);
+        ZGPU_HIP_CHECK(hipGetLastError());
+        uint32_t flag = 0;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(&flag, d_cnt + 4, 4, hipMemcpyDeviceToHost, st));
+        prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        if (dbg) fprintf(stderr, "[spec] resolved %u pages, flag %u\n", npages, flag);
+        if (flag) return 1;
+        res->out_bytes = total; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0;
+        res->in_used = end_byte; res->stream_end = stream_mode ? 1 : 0; res->incomplete = 0;
+        g_spec_done++;
+        return output_checksums(e, d_out, total, out_cap, res, st);
+    }
+}
+} // namespace zgpu
 
 // Decode a raw deflate body made of full-flush-separated segments without a side table.  Candidate boundaries are the
 // marker positions; a candidate that is not a real boundary (the pattern can occur inside stored or coded data) makes its
@@ -979,12 +1362,19 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
         if (last_bad && res->error_msg == kMsgTruncated) return rc; // the body stops early (strict mode; stream mode reports it as incomplete)
         const bool window_kept = res->error_msg == kMsgTooFar || res->error_msg == kMsgOutput;
         if (!last_bad && !window_kept && pass < 4) { b.erase(b.begin() + res->first_bad_chunk + 1); continue; } // not a boundary after all
-        if (in_bytes >= (1ull << 29)) return rc;
         whole = true;
         break;
     }
     if (whole) {
+        const int src = inflate_spec_run(e, d_in, in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode);
+        if (src != 1 && src != ZGPU_OK) return src;
+        whole = src == 1;
+        if (!whole) b.assign({0, in_bytes});
+    }
+    if (whole) {
+        if (in_bytes >= (1ull << 29)) return engine_fail(e, ZGPU_DATA_ERROR, "stream too long for the one-workgroup decoder");
         b.assign({0, in_bytes});
+        g_whole_done++;
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_offs, b.data(), b.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         rc = inflate_run(e, d_in, in_bytes, d_offs, 1, kWholeStream, engine_stage_out(e), out_cap, res, st, stream_mode, b.data());
         if (rc != ZGPU_OK) {
@@ -1001,6 +1391,7 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
 extern "C" {
 #pragma GCC visibility push(default)
 const char *zgpu_inflate_message(uint32_t index) { return index < kMsgCount ? kInfMessages[index] : ""; }
+uint64_t zgpu_inflate_spec_count(int which) { return which == 0 ? g_spec_done.load() : which == 1 ? g_whole_done.load() : 0; }
 int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size, uint64_t *offsets, uint64_t max_chunks,
                                   uint64_t *nchunks)
 {

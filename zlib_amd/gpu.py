@@ -72,6 +72,9 @@ def load_library():
     L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
     L.zgpu_inflate_host.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
     L.zgpu_inflate_find_chunks_host.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64)]
+    L.zgpu_inflate_stream_host2.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
+    L.zgpu_inflate_spec_count.argtypes = [C.c_int]
+    L.zgpu_inflate_spec_count.restype = u64
     L.zgpu_inflate_message.argtypes = [u32]
     L.zgpu_inflate_message.restype = C.c_char_p
     L.zgpu_adler32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
@@ -195,6 +198,25 @@ class Engine:
             msg = self.L.zgpu_inflate_message(res.error_msg).decode() if rc == -3 else self.L.zgpu_engine_error(self.h).decode()
             raise EngineError(rc, msg)
         return out[: res.out_bytes].tobytes()
+
+    def inflate_stream_host(self, body, out_cap, flags=0, out=None):
+        """A raw deflate body without a side table (zgpu_inflate_stream_host2): split at its flush markers if it has them, in pieces at
+        block starts found by search if it is long enough, by one workgroup otherwise.  Returns the bytes; self.last_inflate has the rest."""
+        import numpy as np
+        arr = np.frombuffer(body, dtype=np.uint8)
+        given = out is not None
+        if not given:
+            out = np.empty(max(out_cap, 1), dtype=np.uint8)
+        res = InflateResult()
+        rc = self.L.zgpu_inflate_stream_host2(self.h, arr.ctypes.data, arr.size, flags, out.ctypes.data, out_cap, C.byref(res))
+        self.last_inflate = res
+        if rc != 0:
+            msg = self.L.zgpu_inflate_message(res.error_msg).decode() if rc == -3 else self.L.zgpu_engine_error(self.h).decode()
+            raise EngineError(rc, msg)
+        return out[: res.out_bytes] if given else out[: res.out_bytes].tobytes()
+
+    def spec_counts(self):
+        return int(self.L.zgpu_inflate_spec_count(0)), int(self.L.zgpu_inflate_spec_count(1))
 
     def inflate_device(self, d_in, n, d_offsets, nchunks, d_out, out_cap, chunk_size=CHUNK, stream=None):
         res = InflateResult()
