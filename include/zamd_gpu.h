@@ -159,7 +159,8 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
 int zgpu_inflate_find_chunks_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t chunk_size,
                                   uint64_t *offsets, uint64_t max_chunks, uint64_t *nchunks);
 /* The same search, delivering the decoded bytes: raw deflate body in (no zlib header / trailer), bytes out.  A body
- * that does not split into independent segments (any other producer's stream) is decoded as ZGPU_WHOLE_STREAM. */
+ * that does not split into independent segments (any other producer's stream) is decoded in pieces found by search (see
+ * zgpu_inflate_spec_count below) or, failing that, as ZGPU_WHOLE_STREAM. */
 int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, void *out, uint64_t out_cap,
                              zgpu_inflate_result *res);
 /* The same for the REST OF A STREAM (flags = ZGPU_INF_STREAM): `in` starts at a block boundary and may reach beyond the end of the

@@ -289,14 +289,19 @@ template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b
     // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
     if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) return kMsgCodeLens;
     wave_sync();
-    for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
+    // the 128 entries of the code-length code's table live in two registers per lane from here on: a look-up is a v_readlane, not a round trip to LDS
+    const uint32_t cl0 = L.dtab[lane], cl1 = L.dtab[64 + lane];
     wave_sync();
+    for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
     uint32_t have = 0, prev = 0;
     while (have < nlen + ndist) {
         stage_fill(b, L.stage, lane);
         refill(b, L.stage);
-        const uint32_t s = decode_sym(b, L.dtab, 7);
-        if (s == 0xFFFFu) return kMsgCodeLens;
+        const uint32_t ci = peek(b, 7);
+        const uint32_t ce = ci < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)cl0, (int)ci) : (uint32_t)__builtin_amdgcn_readlane((int)cl1, (int)(ci - 64));
+        if (!ce) return kMsgCodeLens;
+        drop(b, ce & 255u);
+        const uint32_t s = ce >> 8;
         if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
         uint32_t rep, val = 0;
         refill(b, L.stage);
@@ -310,6 +315,24 @@ template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b
         prev = val; have += rep;
     }
     wave_sync();
+    // inflate_table's verdict on the two sets of lengths (inftrees.c:106-138: over-subscribed, or incomplete with more than a single one-bit
+    // code), taken by all lanes together before lane 0 builds anything: the block finder comes here with thousands of headers that are none
+    {
+        uint32_t kl = 0, kd = 0, ml = 0, md = 0;
+        for (uint32_t i = lane; i < nlen + ndist; i += 64) {
+            const uint32_t l = L.lens[i], k = l ? (32768u >> l) : 0u;
+            if (i < nlen) { kl += k; ml = l > ml ? l : ml; } else { kd += k; md = l > md ? l : md; }
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            kl += (uint32_t)__shfl_xor((int)kl, sh); kd += (uint32_t)__shfl_xor((int)kd, sh);
+            const uint32_t a = (uint32_t)__shfl_xor((int)ml, sh), c = (uint32_t)__shfl_xor((int)md, sh);
+            ml = a > ml ? a : ml; md = c > md ? c : md;
+        }
+        kl = uni(kl); kd = uni(kd); ml = uni(ml); md = uni(md);
+        if (ml && (kl > 32768u || (kl < 32768u && ml != 1))) return kMsgLitLens;
+        if (md && (kd > 32768u || (kd < 32768u && md != 1))) return kMsgDists;
+    }
     if (build_table(L, L.lens, nlen, 1, kLBits, L.ltab, L.lsym, L.lcount, lane)) return kMsgLitLens;
     lrows = load_rows(L, L.lcount, lane);
     wave_sync();
@@ -1048,109 +1071,175 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
         }
         wave_sync();
         const uint64_t blk_hi = blk + kScanBytes * 8 < hi_bit ? blk + kScanBytes * 8 : hi_bit;
-    for (uint64_t base = blk; base < blk_hi && result == ~0ull; base += 64) {
-        const uint64_t p = base + lane;
-        const uint32_t rel = (uint32_t)(p - blk), wi = rel >> 5, sh = rel & 31u;
-        uint32_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = scan[wi + k];
-        const uint32_t b0 = __builtin_amdgcn_alignbit(w[1], w[0], sh), b1 = __builtin_amdgcn_alignbit(w[2], w[1], sh), b2 = __builtin_amdgcn_alignbit(w[3], w[2], sh);
-        // BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29, HCLEN; the code-length code complete (inftrees.c:106-138: sum of 2^-len == 1)
-        const uint32_t nlen = (b0 >> 3) & 31u, ndist = (b0 >> 8) & 31u, ncode = ((b0 >> 13) & 15u) + 4;
-        uint64_t y = ((((uint64_t)b1 << 32) | b0) >> 17) | ((uint64_t)b2 << 47);
-        y &= (1ull << (3 * ncode)) - 1; // lengths that are not sent are 0
-        const uint32_t ylo = (uint32_t)y, ymid = (uint32_t)(y >> 30);
-        uint32_t kraft = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 10; i++) kraft += (128u >> ((ylo >> (3 * i)) & 7u)) & 127u;  // a length of 0 counts nothing
-#pragma unroll
-        for (uint32_t i = 0; i < 9; i++) kraft += (128u >> ((ymid >> (3 * i)) & 7u)) & 127u;
-        const bool ok = p + 17 + 3 * ncode < hi_bit && (b0 & 7u) == 4u && nlen <= 29 && ndist <= 29 && kraft == 128;
-        uint64_t m = __ballot(ok);
-        while (m) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
-            const uint64_t cand = base + l;
-            BitSrc b;
-            b.g32 = g32; b.gdwords = gdwords; b.d0 = cand >> 5; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
-            const uint64_t left = total_bits - (cand & ~31ull);
-            b.seg_bits = left > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)left;
+        // Three sieves.  (1) every lane, its own bit offset: BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29 -- one offset in nine passes; the survivors
+        // are listed in LDS in offset order.  (2) whenever 64 are listed (and at the end of the block), one per lane: the code-length code must be
+        // complete (inftrees.c:106-138: sum of 2^-len == 1).  (3) what is left, in order, through the decoder's own header parse.
+        uint32_t listed = 0;
+        uint16_t *list = reinterpret_cast<uint16_t *>(L.tok); // 128 entries are used at most (63 left over + 64 new)
+        for (uint64_t base = blk; base < blk_hi + 64 && result == ~0ull; base += 64) {
+            if (base < blk_hi) {
+                const uint32_t rel = (uint32_t)(base - blk) + lane, wi = rel >> 5, sh = rel & 31u;
+                const uint32_t b0 = __builtin_amdgcn_alignbit(scan[wi + 1], scan[wi], sh);
+                const bool pre = base + lane < blk_hi && (b0 & 7u) == 4u && ((b0 >> 3) & 31u) <= 29 && ((b0 >> 8) & 31u) <= 29;
+                const uint64_t pm = __ballot(pre);
+                if (pre) list[listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))] = (uint16_t)rel;
+                listed += (uint32_t)__builtin_popcountll(pm);
+                if (listed < 64 && base + 64 < blk_hi) continue;
+            }
             wave_sync();
-            stage_fill(b, L.stage, lane);
-            wave_sync();
-            prime(b, L.stage);
-            refill(b, L.stage); refill(b, L.stage);
-            drop(b, (uint32_t)cand & 31u);
-            drop(b, 3);
-            CodeRows lr{}, dr{};
-            const uint32_t err = dynamic_header(L, b, lane, lr, dr);
-            wave_sync();
-            // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
-            if (!err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits) { result = cand; break; }
+            while (listed && result == ~0ull && (listed >= 64 || base + 64 >= blk_hi)) {
+                const uint32_t take = listed < 64 ? listed : 64;
+                const uint32_t rel = lane < take ? list[lane] : 0u, wi = rel >> 5, sh = rel & 31u;
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = scan[wi + k];
+                const uint32_t b0 = __builtin_amdgcn_alignbit(w[1], w[0], sh), b1 = __builtin_amdgcn_alignbit(w[2], w[1], sh), b2 = __builtin_amdgcn_alignbit(w[3], w[2], sh);
+                const uint32_t ncode = ((b0 >> 13) & 15u) + 4;
+                uint64_t y = ((((uint64_t)b1 << 32) | b0) >> 17) | ((uint64_t)b2 << 47);
+                y &= (1ull << (3 * ncode)) - 1; // lengths that are not sent are 0
+                const uint32_t ylo = (uint32_t)y, ymid = (uint32_t)(y >> 30);
+                uint32_t kraft = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 10; i++) kraft += (128u >> ((ylo >> (3 * i)) & 7u)) & 127u; // a length of 0 counts nothing
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) kraft += (128u >> ((ymid >> (3 * i)) & 7u)) & 127u;
+                const bool ok = lane < take && blk + rel + 17 + 3 * ncode < hi_bit && kraft == 128;
+                uint64_t m = __ballot(ok);
+                // the rest of the list moves to the front (before the header parse: it uses L.tok's neighbours, not L.tok)
+                const uint32_t moved = lane + take < listed ? list[lane + take] : 0u;
+                wave_sync();
+                if (lane + take < listed) list[lane] = (uint16_t)moved;
+                listed -= take;
+                wave_sync();
+                while (m) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
+                    const uint64_t cand = blk + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
+                    BitSrc b;
+                    b.g32 = g32; b.gdwords = gdwords; b.d0 = cand >> 5; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+                    const uint64_t left = total_bits - (cand & ~31ull);
+                    b.seg_bits = left > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)left;
+                    wave_sync();
+                    stage_fill(b, L.stage, lane);
+                    wave_sync();
+                    prime(b, L.stage);
+                    refill(b, L.stage); refill(b, L.stage);
+                    drop(b, (uint32_t)cand & 31u);
+                    drop(b, 3);
+                    CodeRows lr{}, dr{};
+                    const uint32_t err = dynamic_header(L, b, lane, lr, dr);
+                    wave_sync();
+                    // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
+                    if (!err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits) { result = cand; break; }
+                }
+            }
         }
-    }
     }
     if (lane == 0) found[t - 1] = result;
 }
 
-// Piece by piece: window[i] = the last 32 KiB of the output up to the end of piece i, from the piece's tail (symbols) and window[i - 1].
-// out_start[i] = where piece i begins in the output.  flag[0] != 0: a marker named a byte in front of the stream's first (the stream is damaged
-// or a start was false: the caller falls back).  One workgroup; the windows alternate between two LDS buffers.
-__global__ void __launch_bounds__(1024) spec_window_kernel(const uint16_t *__restrict__ tails, const SpecEnd *__restrict__ ends, uint32_t nseg, uint32_t dict_len,
-                                                           uint8_t *__restrict__ windows, uint64_t *__restrict__ out_start, uint32_t *flag)
+// The windows: window[i] = the last 32 KiB of the output up to the end of piece i = piece i's tail with its markers looked up in window[i - 1] -- a
+// chain as long as the stream has pieces.  Looking up is associative, so the chain is cut into groups:
+//   spec_window_rel_kernel  one workgroup per group: piece by piece, the tail with its markers looked up in the previous RELATIVE window, whose own
+//                           markers name bytes of the window in front of the group (kept in place of the tail);
+//   spec_window_grp_kernel  one workgroup: group by group, the window behind the group's last piece as bytes (the only chain over the whole stream);
+//   spec_window_abs_kernel  one workgroup per piece: its relative window with the markers looked up in the window in front of its group.
+// A marker that names a byte in front of the stream's first is found out by spec_resolve_kernel (every produced byte passes there).
+__device__ inline void window_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } // (loads of the next tail stay in flight)
+__device__ inline uint4 lookup8(uint4 q, const uint16_t *prev) // eight symbols; markers replaced by prev[index] (a symbol again)
 {
-    __shared__ uint8_t win[2][kOutRing];
-    const uint32_t tid = threadIdx.x;
-    uint64_t pos = 0; // output bytes in front of piece i
-    uint32_t bad = 0;
-    constexpr uint32_t kPer = kOutRing / 8 / 1024; // vectors of 8 symbols per thread
-    uint4 nxt[kPer];
-    uint32_t nxt_out = nseg ? ends[0].out_bytes : 0u;
+    uint32_t ws[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (uint32_t r = 0; r < kPer; r++) nxt[r] = nseg ? reinterpret_cast<const uint4 *>(tails)[r * 1024 + tid] : make_uint4(0, 0, 0, 0);
-    for (uint32_t i = 0; i < nseg; i++) {
-        const uint8_t *prev = win[(i + 1) & 1];
-        uint8_t *cur = win[i & 1];
+    for (int k = 0; k < 4; k++) {
+        uint32_t lo = ws[k] & 0xFFFFu, hi = ws[k] >> 16;
+        if (lo & 0x8000u) lo = prev[lo & 0x7FFFu];
+        if (hi & 0x8000u) hi = prev[hi & 0x7FFFu];
+        ws[k] = lo | (hi << 16);
+    }
+    return make_uint4(ws[0], ws[1], ws[2], ws[3]);
+}
+__global__ void __launch_bounds__(1024) spec_window_rel_kernel(uint16_t *tails, uint32_t nseg, uint32_t group)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint16_t *win = reinterpret_cast<uint16_t *>(lds_raw); // two windows of kOutRing symbols
+    const uint32_t tid = threadIdx.x, first = blockIdx.x * group, last = first + group < nseg ? first + group : nseg;
+    if (first >= nseg) return;
+    constexpr uint32_t kPer = kOutRing / 8 / 1024;
+    uint4 nxt[kPer];
+#pragma unroll
+    for (uint32_t r = 0; r < kPer; r++) nxt[r] = reinterpret_cast<const uint4 *>(tails + (uint64_t)first * kOutRing)[r * 1024 + tid];
+    for (uint32_t i = first; i < last; i++) {
+        const uint16_t *prev = win + ((i + 1) & 1) * kOutRing;
+        uint16_t *cur = win + (i & 1) * kOutRing;
         uint4 q4[kPer];
 #pragma unroll
         for (uint32_t r = 0; r < kPer; r++) q4[r] = nxt[r];
-        const uint32_t out_i = nxt_out;
-        if (i + 1 < nseg) { // the next piece's tail is on its way while this one is resolved (the chain is as long as the stream has pieces)
-            const uint4 *t4n = reinterpret_cast<const uint4 *>(tails + (uint64_t)(i + 1) * kOutRing);
+        if (i + 1 < last) {
 #pragma unroll
-            for (uint32_t r = 0; r < kPer; r++) nxt[r] = t4n[r * 1024 + tid];
-            nxt_out = ends[i + 1].out_bytes;
+            for (uint32_t r = 0; r < kPer; r++) nxt[r] = reinterpret_cast<const uint4 *>(tails + (uint64_t)(i + 1) * kOutRing)[r * 1024 + tid];
         }
-        // bytes of the previous window that exist: index >= kOutRing - (pos + dict_len) (piece 0 holds its dictionary itself)
-        const uint64_t have_prev = i == 0 ? 0 : pos + dict_len, end = pos + out_i, have_cur = end + dict_len;
-        const uint32_t vf_prev = have_prev >= kOutRing ? 0u : kOutRing - (uint32_t)have_prev, vf_cur = have_cur >= kOutRing ? 0u : kOutRing - (uint32_t)have_cur;
 #pragma unroll
         for (uint32_t r = 0; r < kPer; r++) {
-            const uint32_t v = r * 1024 + tid;
-            const uint4 q = q4[r];
-            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
-            uint32_t o8[2] = {0, 0};
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t sym = (ws[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu, j = v * 8 + k;
-                uint32_t byte = sym & 255u;
-                if (sym & 0x8000u) {
-                    const uint32_t idx = sym & 0x7FFFu;
-                    if (idx >= vf_prev) byte = prev[idx];
-                    else { byte = 0; if (j >= vf_cur) bad = 1; } // a produced byte copied from in front of the stream
-                }
-                o8[k >> 2] |= byte << ((k & 3) * 8);
-            }
-            reinterpret_cast<uint2 *>(cur)[v] = make_uint2(o8[0], o8[1]);
-            reinterpret_cast<uint2 *>(windows + (uint64_t)i * kOutRing)[v] = make_uint2(o8[0], o8[1]);
+            const uint4 o = i == first ? q4[r] : lookup8(q4[r], prev); // (the group's first piece is relative to the window in front of the group as it is)
+            reinterpret_cast<uint4 *>(cur)[r * 1024 + tid] = o;
+            if (i != first) reinterpret_cast<uint4 *>(tails + (uint64_t)i * kOutRing)[r * 1024 + tid] = o;
         }
-        if (tid == 0) out_start[i] = pos;
-        pos = end;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the window in LDS; __syncthreads would wait for the next tail's loads as well)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        window_barrier();
     }
-    if (tid == 0) out_start[nseg] = pos;
-    if (bad) atomicOr(flag, 1u);
+}
+__global__ void __launch_bounds__(1024) spec_window_grp_kernel(const uint16_t *__restrict__ tails, uint32_t nseg, uint32_t group, uint8_t *__restrict__ entry)
+{
+    // entry[g] = the window in front of group g, as bytes (group 0: nothing is known, and nothing valid refers to it)
+    __shared__ uint16_t win[2][kOutRing]; // bytes, kept as symbols so that lookup8 serves
+    const uint32_t tid = threadIdx.x, ngroups = (nseg + group - 1) / group;
+    constexpr uint32_t kPer = kOutRing / 8 / 1024;
+    for (uint32_t r = 0; r < kPer; r++) reinterpret_cast<uint4 *>(win[1])[r * 1024 + tid] = make_uint4(0, 0, 0, 0);
+    for (uint32_t r = tid; r < kOutRing / 16; r += 1024) reinterpret_cast<uint4 *>(entry)[r] = make_uint4(0, 0, 0, 0);
+    window_barrier();
+    uint4 nxt[kPer];
+    auto last_of = [&](uint32_t g) { return (g + 1) * group < nseg ? (g + 1) * group - 1 : nseg - 1; };
+#pragma unroll
+    for (uint32_t r = 0; r < kPer; r++) nxt[r] = reinterpret_cast<const uint4 *>(tails + (uint64_t)last_of(0) * kOutRing)[r * 1024 + tid];
+    for (uint32_t g = 0; g + 1 < ngroups; g++) {
+        const uint16_t *prev = win[(g + 1) & 1];
+        uint16_t *cur = win[g & 1];
+        uint4 q4[kPer];
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; r++) q4[r] = nxt[r];
+        if (g + 2 < ngroups) {
+#pragma unroll
+            for (uint32_t r = 0; r < kPer; r++) nxt[r] = reinterpret_cast<const uint4 *>(tails + (uint64_t)last_of(g + 1) * kOutRing)[r * 1024 + tid];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kPer; r++) {
+            uint4 o = lookup8(q4[r], prev);
+            o.x &= 0x00FF00FFu; o.y &= 0x00FF00FFu; o.z &= 0x00FF00FFu; o.w &= 0x00FF00FFu; // (what was a marker in group 0's entry is a byte nobody may use)
+            reinterpret_cast<uint4 *>(cur)[r * 1024 + tid] = o;
+            const uint32_t b0 = (o.x & 255u) | ((o.x >> 8) & 0xFF00u) | ((o.y & 255u) << 16) | ((o.y >> 16) << 24);
+            const uint32_t b1 = (o.z & 255u) | ((o.z >> 8) & 0xFF00u) | ((o.w & 255u) << 16) | ((o.w >> 16) << 24);
+            reinterpret_cast<uint2 *>(entry + (uint64_t)(g + 1) * kOutRing)[r * 1024 + tid] = make_uint2(b0, b1);
+        }
+        window_barrier();
+    }
+}
+__global__ void __launch_bounds__(256) spec_window_abs_kernel(const uint16_t *__restrict__ tails, uint32_t nseg, uint32_t group, const uint8_t *__restrict__ entry,
+                                                              uint8_t *__restrict__ windows)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= nseg) return;
+    const uint8_t *e = entry + (uint64_t)(i / group) * kOutRing;
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(tails + (uint64_t)i * kOutRing);
+    for (uint32_t v = threadIdx.x; v < kOutRing / 8; v += 256) {
+        const uint4 q = t4[v];
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+        uint32_t o8[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t sym = (ws[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const uint32_t byte = (sym & 0x8000u) ? e[sym & 0x7FFFu] : (sym & 255u);
+            o8[k >> 2] |= byte << ((k & 3) * 8);
+        }
+        reinterpret_cast<uint2 *>(windows + (uint64_t)i * kOutRing)[v] = make_uint2(o8[0], o8[1]);
+    }
 }
 
 // One workgroup per page of symbols: to its place in the output, markers through the window of the piece in front.
@@ -1205,6 +1294,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
     if (!opt_in) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsSpec));
         hipFuncSetAttribute(reinterpret_cast<const void *>(spec_find_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsFind));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(spec_window_rel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kOutRing));
         opt_in = true;
     }
     hipEvent_t ev{};
@@ -1237,7 +1327,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
         auto carve = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
         const size_t o_starts = carve((size_t)(nseg + 1) * 8), o_ends = carve((size_t)nseg * sizeof(SpecEnd)), o_ostart = carve((size_t)(nseg + 1) * 8),
                      o_status = carve((size_t)nseg * sizeof(InfStatus)), o_cnt = carve(64), o_owner = carve((size_t)page_cap * 8),
-                     o_win = carve((size_t)nseg * kOutRing), o_tails = carve((size_t)nseg * kOutRing * 2), o_mid = carve((size_t)page_cap * kOutHalf * 2);
+                     o_win = carve((size_t)nseg * kOutRing), o_entry = carve((size_t)(nseg / 8 + 2) * kOutRing), o_tails = carve((size_t)nseg * kOutRing * 2), o_mid = carve((size_t)page_cap * kOutHalf * 2);
         uint8_t *base = static_cast<uint8_t *>(engine_scratch2(e, off));
         if (!base) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; } // (no room for the symbols: the slow way needs none)
         uint64_t *d_starts = reinterpret_cast<uint64_t *>(base + o_starts), *d_ostart = reinterpret_cast<uint64_t *>(base + o_ostart);
@@ -1292,7 +1382,20 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
             continue;
         }
         const uint32_t npages = cnt[0] < page_cap ? cnt[0] : page_cap;
-        hipLaunchKernelGGL(spec_window_kernel, dim3(1), dim3(1024), 0, st, sp.tails, d_ends, used_seg, engine_inflate_dict_len(e), base + o_win, d_ostart, d_cnt + 4);
+        {
+            std::vector<uint64_t> ostart(used_seg + 1);
+            uint64_t pos = 0;
+            for (uint32_t i = 0; i < used_seg; i++) { ostart[i] = pos; pos += ends[i].out_bytes; }
+            ostart[used_seg] = pos;
+            ZGPU_HIP_CHECK(hipMemcpyAsync(d_ostart, ostart.data(), (size_t)(used_seg + 1) * 8, hipMemcpyHostToDevice, st));
+            ZGPU_HIP_CHECK(hipStreamSynchronize(st)); // (ostart is a local)
+            uint32_t group = 8;
+            while (group * group < used_seg) group++;
+            const uint32_t ngroups = (used_seg + group - 1) / group;
+            hipLaunchKernelGGL(spec_window_rel_kernel, dim3(ngroups), dim3(1024), 4 * kOutRing, st, sp.tails, used_seg, group);
+            hipLaunchKernelGGL(spec_window_grp_kernel, dim3(1), dim3(1024), 0, st, sp.tails, used_seg, group, base + o_entry);
+            hipLaunchKernelGGL(spec_window_abs_kernel, dim3(used_seg), dim3(256), 0, st, sp.tails, used_seg, group, base + o_entry, base + o_win);
+        }
         if (npages) hipLaunchKernelGGL(spec_resolve_kernel, dim3(npages), dim3(256), 0, st, sp.mid, sp.page_owner, npages, d_ends, used_seg, base + o_win, d_ostart,
                                        engine_inflate_dict_len(e), d_out, out_cap, d_cnt + 4);
         ZGPU_HIP_CHECK(hipGetLastError());
