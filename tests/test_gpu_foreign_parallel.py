@@ -71,6 +71,21 @@ def test_streams_of_other_shapes(eng):
         assert eng.last_inflate.crc32 == zlib.crc32(want), name
 
 
+def test_deflate_streams_inside_stored_blocks_do_not_derail_the_pieces(eng):
+    """An archive of compressed files compresses to stored blocks that are full of block headers -- none of them a block start of THIS stream.
+    A piece that runs past such a start shows it up; the list of starts is repaired and the pieces decoded again (no one-workgroup fallback)."""
+    text = corpus(eng, 1, 40, 160)
+    inner = b"".join(zlib.compress(text[i:i + (1 << 20)], 6) for i in range(0, len(text), 1 << 20))  # ~3 MiB of deflate streams
+    for name, want in (("stored", inner * 3), ("mixed", text[: 3 << 20] + inner + text[3 << 20: 6 << 20] + inner)):
+        for level in (0, 6):
+            raw = raw_deflate(want, level)
+            before = eng.spec_counts()
+            out = eng.inflate_stream_host(raw, len(want))
+            after = eng.spec_counts()
+            assert out == want, (name, level)
+            assert after[0] == before[0] + 1 and after[1] == before[1], (name, level, before, after)
+
+
 def test_capacity_and_tails(eng):
     import zlib_amd
     data = corpus(eng, 0, 33, 128)

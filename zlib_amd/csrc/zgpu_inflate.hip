@@ -385,8 +385,12 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
     uint64_t seg_lo = offsets[gc], seg_hi = offsets[gc + 1];
     uint32_t bit_lead = 0, stop_bits = 0xFFFFFFFFu; // SPEC: bits of the first byte in front of the start; where the next segment starts, in bits from seg_lo
     bool bad_table;
+    bool at_len = false; // SPEC: the piece starts at the LEN field of a stored block (its header bits lie in front, the piece before checks them)
     if (SPEC) {
-        const uint64_t s0 = seg_lo, s1 = seg_hi;
+        // bit 62 of a start: the position is the (byte-aligned) LEN of a stored block; the piece in front of such a start stops at the first block
+        // boundary that can be that block's: 3 header bits and up to 7 of padding in front of LEN
+        at_len = (seg_lo >> 62) & 1u;
+        const uint64_t s0 = seg_lo & ~(3ull << 62), s1 = ((seg_hi >> 62) & 1u) ? (seg_hi & ~(3ull << 62)) - 10 : seg_hi;
         bad_table = s0 >= s1 || s1 > in_bytes * 8 || s1 - (s0 & ~7ull) >= (1ull << 31);
         seg_lo = s0 >> 3; seg_hi = in_bytes - seg_lo < (1ull << 28) ? in_bytes : seg_lo + (1ull << 28);
         bit_lead = (uint32_t)(s0 & 7u); stop_bits = bad_table ? 0u : (uint32_t)(s1 - seg_lo * 8);
@@ -480,9 +484,13 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
             if (SPEC && org_bits + consumed_bits(b) - lead * 8 >= stop_bits) break; // a block boundary at or behind the next segment's start
             stage_fill(b, L.stage, lane); wave_sync();
             refill(b, L.stage);
-            const uint32_t hdr = peek(b, 3); drop(b, 3);
-            last = hdr & 1; seen_final = seen_final || last;
-            const uint32_t type = hdr >> 1;
+            uint32_t type = 0;
+            if (SPEC && at_len) at_len = false; // (the first block of this piece: stored, not the last, the reader stands at its LEN)
+            else {
+                const uint32_t hdr = peek(b, 3); drop(b, 3);
+                last = hdr & 1; seen_final = seen_final || last;
+                type = hdr >> 1;
+            }
             if (type == 3) { err = kMsgBlockType; break; }
             if (type == 0) {
                 drop(b, b.bits & 7);
@@ -1055,6 +1063,61 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
     const uint32_t *g32 = reinterpret_cast<const uint32_t *>(in); // (the input buffer is a device allocation: aligned)
     const uint64_t gdwords = (in_bytes + 3) >> 2;
     uint64_t result = ~0ull;
+    // does a dynamic block the decoder would accept start at bit `cand` (its three type bits are not looked at)?
+    auto dynamic_at = [&](uint64_t cand) -> bool {
+        BitSrc b;
+        b.g32 = g32; b.gdwords = gdwords; b.d0 = cand >> 5; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
+        const uint64_t left = total_bits - (cand & ~31ull);
+        b.seg_bits = left > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)left;
+        wave_sync();
+        stage_fill(b, L.stage, lane);
+        wave_sync();
+        prime(b, L.stage);
+        refill(b, L.stage); refill(b, L.stage);
+        drop(b, (uint32_t)cand & 31u);
+        drop(b, 3);
+        CodeRows lr{}, dr{};
+        const uint32_t err = dynamic_header(L, b, lane, lr, dr);
+        wave_sync();
+        // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
+        return !err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits;
+    };
+    // Stored blocks: data that does not compress (an archive of compressed files) arrives in them, full of block headers that are none of this
+    // stream's.  The first byte offset B of the region that reads as LEN, ~LEN behind three zero header bits and zero padding, and whose block is
+    // followed by a header that holds as well (stored: LEN, ~LEN again; dynamic: as above) is reported too: the host starts a piece AT its LEN and
+    // strikes the dynamic "starts" found inside the block's bytes.
+    uint64_t stored = ~0ull;
+    {
+        const uint64_t lo_byte = (uint64_t)t * spacing, hi_byte = hi_bit >> 3;
+        for (uint64_t o0 = lo_byte; o0 < hi_byte && stored == ~0ull; o0 += 256) {
+            const uint64_t o = o0 + lane * 4, wi = o >> 2; // (lo_byte is a multiple of 4096, t >= 1: wi >= 1)
+            const uint32_t dp = wi - 1 < gdwords ? g32[wi - 1] : 0u, d0 = wi < gdwords ? g32[wi] : 0u, d1 = wi + 1 < gdwords ? g32[wi + 1] : 0u;
+            uint32_t hit = 0, wsel = 0;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const uint32_t w = k == 0 ? d0 : __builtin_amdgcn_alignbyte(d1, d0, k), pb = k == 0 ? dp >> 24 : (d0 >> (8 * (k - 1))) & 255u;
+                if (((w ^ (w >> 16)) & 0xFFFFu) == 0xFFFFu && (pb >> 5) == 0 && o + k + 4 <= in_bytes && o + k < hi_byte) { hit |= 1u << k; }
+            }
+            uint64_t m = __ballot(hit != 0);
+            while (m && stored == ~0ull) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
+                uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)hit, (int)l);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, (int)l), e1 = (uint32_t)__builtin_amdgcn_readlane((int)d1, (int)l);
+                while (hk && stored == ~0ull) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(hk); hk &= hk - 1;
+                    const uint64_t B = o0 + l * 4 + k;
+                    const uint32_t len = (uint32_t)((((uint64_t)e1 << 32) | e0) >> (8 * k)) & 0xFFFFu;
+                    const uint64_t N = B + 4 + len; // the header behind the block: it begins a byte
+                    if (N + 5 > in_bytes) continue;
+                    const uint32_t hb = in[N], type = (hb >> 1) & 3u;
+                    bool good = false;
+                    if (type == 0) good = ((((uint32_t)in[N + 1] | ((uint32_t)in[N + 2] << 8)) ^ ((uint32_t)in[N + 3] | ((uint32_t)in[N + 4] << 8))) & 0xFFFFu) == 0xFFFFu && (hb >> 3) == 0;
+                    else if (type == 2) good = dynamic_at(N * 8);
+                    if (good) stored = B;
+                }
+            }
+        }
+    }
     // the bytes to scan come through LDS, kScanBytes at a time
     uint32_t *scan = reinterpret_cast<uint32_t *>(L.out);
     const uint4 *g128 = reinterpret_cast<const uint4 *>(in);
@@ -1114,27 +1177,12 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                 while (m) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
                     const uint64_t cand = blk + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
-                    BitSrc b;
-                    b.g32 = g32; b.gdwords = gdwords; b.d0 = cand >> 5; b.filled = 0; b.rd = 0; b.hold = 0; b.bits = 0;
-                    const uint64_t left = total_bits - (cand & ~31ull);
-                    b.seg_bits = left > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)left;
-                    wave_sync();
-                    stage_fill(b, L.stage, lane);
-                    wave_sync();
-                    prime(b, L.stage);
-                    refill(b, L.stage); refill(b, L.stage);
-                    drop(b, (uint32_t)cand & 31u);
-                    drop(b, 3);
-                    CodeRows lr{}, dr{};
-                    const uint32_t err = dynamic_header(L, b, lane, lr, dr);
-                    wave_sync();
-                    // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
-                    if (!err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits) { result = cand; break; }
+                    if (dynamic_at(cand)) { result = cand; break; }
                 }
             }
         }
     }
-    if (lane == 0) found[t - 1] = result;
+    if (lane == 0) { found[t - 1] = result; found[ntargets + t - 1] = stored; }
 }
 
 // The windows: window[i] = the last 32 KiB of the output up to the end of piece i = piece i's tail with its markers looked up in window[i - 1] -- a
@@ -1274,8 +1322,8 @@ __global__ void __launch_bounds__(256) spec_resolve_kernel(const uint16_t *__res
 }
 
 // 0: decoded (res complete); 1: not this way (the caller uses the one-workgroup decoder); anything else: an error of the engine
-static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st,
-                            uint32_t stream_mode)
+static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *h_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res,
+                            hipStream_t st, uint32_t stream_mode)
 {
     static long min_bytes = -1;
     if (min_bytes < 0) { const char *v = getenv("ZGPU_SPEC_MIN_BYTES"); min_bytes = v ? atol(v) : 128 * 1024; }
@@ -1288,7 +1336,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
     const uint64_t fspacing = spacing / 4 < 16384 ? 16384 : (spacing / 4 + 4095) & ~4095ull;
     const uint32_t ntargets = (uint32_t)((in_bytes - 1) / fspacing);
     if (ntargets < 3) return 1;
-    uint64_t *d_found = static_cast<uint64_t *>(engine_scratch(e, (size_t)ntargets * 8 + 64));
+    uint64_t *d_found = static_cast<uint64_t *>(engine_scratch(e, (size_t)ntargets * 16 + 64));
     if (!d_found) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
     static bool opt_in = false;
     if (!opt_in) {
@@ -1300,14 +1348,45 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
     hipEvent_t ev{};
     prof_span_begin(e, st, &ev);
     hipLaunchKernelGGL(spec_find_kernel, dim3(ntargets), dim3(64), sizeof(InflateLdsFind), st, d_in, in_bytes, fspacing, ntargets, d_found);
-    std::vector<uint64_t> starts(ntargets + 2);
-    ZGPU_HIP_CHECK(hipMemcpyAsync(starts.data() + 1, d_found, (size_t)ntargets * 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint64_t> found(2 * (size_t)ntargets);
+    ZGPU_HIP_CHECK(hipMemcpyAsync(found.data(), d_found, found.size() * 8, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
-    starts[0] = 0;
-    size_t n = 1;
-    for (uint32_t i = 1; i <= ntargets; i++) if (starts[i] != ~0ull && starts[i] >= starts[n - 1] + spacing * 6 && starts[i] + spacing * 2 < in_bytes * 8) starts[n++] = starts[i];
-    starts[n] = in_bytes * 8;
-    const uint32_t nseg = (uint32_t)n;
+    // starts: bit positions; kind 1 = the LEN of a stored block (a byte position; the block's header bits lie up to 10 bits in front)
+    const uint64_t kStoredFlag = 1ull << 62;
+    std::vector<uint64_t> starts;
+    std::vector<uint8_t> kind;
+    {
+        // what lies inside a stored block the finders vouch for is data, whatever it looks like
+        std::vector<std::pair<uint64_t, uint64_t>> raw; // [first bit, behind the last bit) of stored data
+        for (uint32_t i = 0; i < ntargets; i++) {
+            const uint64_t B = found[ntargets + i];
+            if (B != ~0ull && B + 4 <= in_bytes) raw.emplace_back(B * 8, (B + 4 + ((uint64_t)h_in[B] | ((uint64_t)h_in[B + 1] << 8))) * 8);
+        }
+        std::vector<std::pair<uint64_t, uint8_t>> all;
+        for (uint32_t i = 0; i < ntargets; i++) {
+            const uint64_t d = found[i], B = found[ntargets + i];
+            if (B != ~0ull) all.emplace_back(B * 8, (uint8_t)1);
+            if (d == ~0ull) continue;
+            // (raw ascends with the finders; a stored block is at most 64 KiB and the finders stand 16 KiB apart or more: a few entries can reach d)
+            size_t q = (size_t)(std::upper_bound(raw.begin(), raw.end(), std::pair<uint64_t, uint64_t>(d, ~(uint64_t)0)) - raw.begin());
+            bool inside = false;
+            for (int back = 0; back < 8 && q > 0; back++) { q--; inside = inside || (raw[q].first <= d && d < raw[q].second); }
+            if (!inside) all.emplace_back(d, (uint8_t)0);
+        }
+        std::sort(all.begin(), all.end());
+        starts.push_back(0); kind.push_back(0);
+        for (const auto &c : all)
+            if (c.first >= starts.back() + spacing * 6 && c.first + spacing * 2 < in_bytes * 8) { starts.push_back(c.first); kind.push_back(c.second); }
+        starts.push_back(in_bytes * 8); kind.push_back(0);
+    }
+    uint32_t nseg = (uint32_t)starts.size() - 1;
+    // does the piece that ended at bit `eb` hand over to start j?
+    auto links = [&](uint64_t eb, size_t j) -> bool {
+        if (!kind[j]) return eb == starts[j];
+        if (eb + 3 > starts[j] || eb + 10 < starts[j]) return false;
+        for (uint64_t q = eb; q < starts[j]; q++) if ((h_in[q >> 3] >> (q & 7)) & 1u) return false; // BFINAL 0, stored, padding of zeros
+        return true;
+    };
     static const bool dbg = getenv("ZGPU_SPEC_DEBUG") != nullptr;
     if (dbg) {
         fprintf(stderr, "[spec] %llu bytes, spacing %llu, %u targets, %u pieces; first starts:", (unsigned long long)in_bytes, (unsigned long long)spacing, ntargets, nseg);
@@ -1317,7 +1396,8 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
     if (nseg < 3) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
     // pages: what the output can hold, or -- when the caller's buffer is far larger than this stream can fill -- eight times the input first
     uint64_t guess = in_bytes * 8 + (16u << 20);
-    for (int attempt = 0;; attempt++) {
+    int repairs = 0;
+    for (int attempt = 0;;) {
         const uint64_t room = out_cap < guess ? out_cap : guess;
         const uint64_t pages64 = room / kOutHalf + nseg + 2;
         if (pages64 >= 0xFFFFFFFFull) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
@@ -1336,7 +1416,9 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
         SpecArgs sp{};
         sp.mid = reinterpret_cast<uint16_t *>(base + o_mid); sp.page_owner = reinterpret_cast<uint64_t *>(base + o_owner); sp.page_count = d_cnt; sp.page_cap = page_cap;
         sp.tails = reinterpret_cast<uint16_t *>(base + o_tails); sp.ends = d_ends;
-        ZGPU_HIP_CHECK(hipMemcpyAsync(d_starts, starts.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, st));
+        std::vector<uint64_t> up(starts);
+        for (size_t i = 0; i < up.size(); i++) if (kind[i]) up[i] |= kStoredFlag;
+        ZGPU_HIP_CHECK(hipMemcpy(d_starts, up.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice));
         ZGPU_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 64, st));
         ZGPU_HIP_CHECK(hipMemsetAsync(d_ends, 0xFF, (size_t)nseg * sizeof(SpecEnd), st));
         hipLaunchKernelGGL(inflate_kernel_t<true>, dim3(nseg), dim3(128), sizeof(InflateLdsSpec), st, d_in, in_bytes, d_starts, 0ull, nseg, ~0ull, kWholeStream,
@@ -1353,7 +1435,32 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
             if (ends[i].flags >> 8) break;               // an error (or never written)
             total += ends[i].out_bytes; used_seg = i + 1; dry = dry || (ends[i].flags & 2u);
             if (ends[i].flags & 1u) { ended = true; break; }
-            if (i + 1 == nseg || ends[i].end_bit != starts[i + 1]) break;
+            if (i + 1 == nseg || !links(ends[i].end_bit, i + 1)) break;
+        }
+        // A piece that ran past the next start (or several): those were no block starts -- a deflate stream inside a stored block looks like one, and so
+        // does one pattern in 10^9 or so.  Every piece on the chain so far began at a real boundary, so where the last one ended is one too: the false starts go,
+        // that boundary becomes a start unless it is one, and the pieces are decoded again (three times at most; then the one-workgroup decoder).
+        if (!ended && used_seg >= 1 && used_seg < nseg && !(ends[used_seg - 1].flags >> 8) && !links(ends[used_seg - 1].end_bit, used_seg) && repairs < 3) {
+            std::vector<uint64_t> fixed(starts.begin(), starts.begin() + used_seg);
+            std::vector<uint8_t> fkind(kind.begin(), kind.begin() + used_seg);
+            uint32_t i = used_seg - 1;
+            for (;;) { // follow the chain as far as it goes over the starts that are real
+                const uint64_t eb = ends[i].end_bit;
+                if (eb >= in_bytes * 8) break;
+                const uint32_t j = (uint32_t)(std::lower_bound(starts.begin() + i + 1, starts.begin() + nseg, eb) - starts.begin());
+                if (j < nseg && links(eb, j) && !(ends[j].flags >> 8) && !(ends[j].flags & 1u)) { fixed.push_back(starts[j]); fkind.push_back(kind[j]); i = j; continue; }
+                fixed.push_back(eb); fkind.push_back(0);
+                for (uint32_t k = j; k < nseg; k++) if (starts[k] > eb + 10) { fixed.push_back(starts[k]); fkind.push_back(kind[k]); } // (unchecked from here on)
+                break;
+            }
+            if (dbg) fprintf(stderr, "[spec] chain broke behind piece %u (end %llu, next start %llu): %u pieces -> %zu, decoding again\n", used_seg - 1,
+                             (unsigned long long)ends[used_seg - 1].end_bit, (unsigned long long)starts[used_seg], nseg, fixed.size());
+            fixed.push_back(in_bytes * 8); fkind.push_back(0);
+            starts.swap(fixed); kind.swap(fkind);
+            nseg = (uint32_t)starts.size() - 1;
+            repairs++;
+            if (nseg < 2) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+            continue;
         }
         const uint64_t end_byte = ended ? (ends[used_seg - 1].end_bit + 7) >> 3 : 0;
         if (dbg) {
@@ -1362,7 +1469,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
                 fprintf(stderr, "[spec]   piece %u: start %llu end %llu next %llu out %u flags %#x\n", i, (unsigned long long)starts[i], (unsigned long long)ends[i].end_bit,
                         (unsigned long long)starts[i + 1], ends[i].out_bytes, ends[i].flags);
         }
-        if (!ended && stream_mode && used_seg + 1 == nseg && (ends[nseg - 1].flags >> 8) == kMsgTruncated && ends[used_seg - 1].end_bit == starts[used_seg]) {
+        if (!ended && stream_mode && used_seg >= 1 && used_seg + 1 == nseg && (ends[nseg - 1].flags >> 8) == kMsgTruncated && links(ends[used_seg - 1].end_bit, used_seg)) {
             // every piece chained and the last one ran out of input inside a block: the stream is not all there yet (one workgroup would say the same)
             prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
             engine_collect(e);
@@ -1379,6 +1486,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_byt
         if (dry) { // the pool was sized from the guess: now the size is known
             if (attempt) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
             guess = total + kOutHalf;
+            attempt++;
             continue;
         }
         const uint32_t npages = cnt[0] < page_cap ? cnt[0] : page_cap;
@@ -1469,7 +1577,7 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
         break;
     }
     if (whole) {
-        const int src = inflate_spec_run(e, d_in, in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode);
+        const int src = inflate_spec_run(e, d_in, hin, in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode);
         if (src != 1 && src != ZGPU_OK) return src;
         whole = src == 1;
         if (!whole) b.assign({0, in_bytes});
