@@ -25,6 +25,7 @@ namespace zgpu {
 #define ZGPU_HUFF_THREADS 128
 #endif
 constexpr int kThreads = ZGPU_HUFF_THREADS;
+constexpr uint32_t kEmitPer = 4, kEmitRound = kThreads * kEmitPer; // token emission: rounds of kEmitRound tokens, kEmitPer consecutive ones per lane
 
 // Heap entries are packed: frequency << 16 | depth << 10 | node.  The reference orders nodes by (frequency, depth) with
 // "<=" deciding ties (smaller(), trees.c:451-453), which on packed entries is one comparison of entry >> 10 -- and a
@@ -294,6 +295,8 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
     __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
     __shared__ uint32_t tmp[4];
+    __shared__ __attribute__((aligned(16))) uint32_t tokbuf[kEmitRound];          // one round of tokens, so that global reads are coalesced and lanes still own runs
+    __shared__ uint32_t obuf[(kEmitRound * 48 + 31 + 31) / 32 + 1];               // the round's bits (a token is 48 bits at most), assembled with LDS atomics
     __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
     __shared__ uint64_t sh_bitpos;
 
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
     if (tid == 0) sh_bitpos = 0;
+    for (uint32_t i = tid; i < sizeof(obuf) / 4; i += kThreads) obuf[i] = 0;
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
@@ -318,10 +322,17 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         for (uint32_t i = tid; i < kLCodes + kDCodes + 2; i += kThreads) hist[i] = 0;
         __syncthreads();
         uint32_t bytes = 0;
-        for (uint32_t i = t0 + tid; i < t1; i += kThreads) {
-            uint32_t t = tok[i], dist = t >> 8, lc = t & 255;
-            if (dist == 0) { atomicAdd(&hist[lc], 1u); bytes += 1; }
-            else { uint32_t c, xl, dc, xd; len_code_of(lc, c, xl); dist_code_bits(dist - 1, dc, xd); atomicAdd(&hist[257 + c], 1u); atomicAdd(&hist[kLCodes + dc], 1u); bytes += lc + 3; }
+        for (uint32_t i0 = t0 + tid; i0 < t1; i0 += 4 * kThreads) { // (four loads in flight: one at a time this loop is one memory latency per token)
+            uint32_t tv[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) tv[k] = i0 + k * kThreads < t1 ? tok[i0 + k * kThreads] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (i0 + k * kThreads >= t1) continue;
+                const uint32_t t = tv[k], dist = t >> 8, lc = t & 255;
+                if (dist == 0) { atomicAdd(&hist[lc], 1u); bytes += 1; }
+                else { uint32_t c, xl, dc, xd; len_code_of(lc, c, xl); dist_code_bits(dist - 1, dc, xd); atomicAdd(&hist[257 + c], 1u); atomicAdd(&hist[kLCodes + dc], 1u); bytes += lc + 3; }
+            }
         }
         const uint32_t stored_len = block_reduce_add(bytes, tmp);
         __syncthreads();
@@ -397,18 +408,50 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
                 if (tid < kDCodes) { dcode[tid] = kTables.sd_code[tid]; dlen[tid] = 5; }
                 __syncthreads();
             }
-            // every lane owns a contiguous run of tokens
-            const uint32_t per = (nt + kThreads - 1) / kThreads;
-            const uint32_t a = t0 + (tid * per < nt ? tid * per : nt), z = t0 + ((tid + 1) * per < nt ? (tid + 1) * per : nt);
-            uint32_t mybits = 0;
-            for (uint32_t i = a; i < z; i++) { uint64_t v; uint32_t nb; token_bits(tok[i], lcode, llen, dcode, dlen, v, nb); mybits += nb; }
-            if (tid == kThreads - 1) mybits += llen[kEndBlock];
-            uint32_t total, off = block_exclusive_scan(mybits, tmp, &total);
-            BitWriter bw; bw.begin(out, bitpos + off);
-            for (uint32_t i = a; i < z; i++) { uint64_t v; uint32_t nb; token_bits(tok[i], lcode, llen, dcode, dlen, v, nb); bw.put64(v, nb); }
-            if (tid == kThreads - 1) bw.put(lcode[kEndBlock], llen[kEndBlock]);
-            bw.finish();
-            bitpos += total;
+            // Rounds of kEmitRound tokens (the end-of-block code is the token behind the last): read coalesced into LDS, kEmitPer consecutive ones
+            // per lane sized and coded once, a prefix scan for the bit offsets, the bits put together in LDS (ds_or), the round's words stored
+            // coalesced -- the first and the last, shared with what lies in front and behind, by atomic OR (the slot is zero-initialised).
+            for (uint32_t r0 = 0; r0 <= nt; r0 += kEmitRound) {
+                uint32_t tv[kEmitPer];
+#pragma unroll
+                for (uint32_t k = 0; k < kEmitPer; k++) { const uint32_t j = r0 + k * kThreads + tid; tv[k] = j < nt ? tok[t0 + j] : 0u; }
+#pragma unroll
+                for (uint32_t k = 0; k < kEmitPer; k++) tokbuf[k * kThreads + tid] = tv[k];
+                __syncthreads();
+                const uint4 mine = reinterpret_cast<const uint4 *>(tokbuf)[tid];
+                const uint32_t mt[4] = {mine.x, mine.y, mine.z, mine.w};
+                uint64_t v[kEmitPer]; uint32_t nb[kEmitPer], mybits = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kEmitPer; k++) {
+                    const uint32_t j = r0 + tid * kEmitPer + k;
+                    v[k] = 0; nb[k] = 0;
+                    if (j < nt) token_bits(mt[k], lcode, llen, dcode, dlen, v[k], nb[k]);
+                    else if (j == nt) { v[k] = lcode[kEndBlock]; nb[k] = llen[kEndBlock]; }
+                    mybits += nb[k];
+                }
+                uint32_t total, off = block_exclusive_scan(mybits, tmp, &total);
+                const uint32_t sh0 = (uint32_t)(bitpos & 31);
+                uint32_t at = sh0 + off;
+#pragma unroll
+                for (uint32_t k = 0; k < kEmitPer; k++) {
+                    if (nb[k]) {
+                        const uint32_t w = at >> 5, sh = at & 31;
+                        atomicOr(&obuf[w], (uint32_t)(v[k] << sh));
+                        if (sh + nb[k] > 32) atomicOr(&obuf[w + 1], (uint32_t)(v[k] >> (32 - sh)));
+                        if (sh + nb[k] > 64) atomicOr(&obuf[w + 2], (uint32_t)(v[k] >> (64 - sh)));
+                    }
+                    at += nb[k];
+                }
+                __syncthreads();
+                const uint32_t nwords = (sh0 + total + 31) >> 5;
+                uint32_t *dstw = out + (bitpos >> 5);
+                for (uint32_t w = tid; w < nwords; w += kThreads) {
+                    const uint32_t x = obuf[w];
+                    obuf[w] = 0;
+                    if (w == 0 || w + 1 == nwords) { if (x) atomicOr(&dstw[w], x); } else dstw[w] = x;
+                }
+                bitpos += total;
+            }
         }
         block_start += stored_len;
         __syncthreads();
