@@ -289,14 +289,17 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_huf_time(unsig
 
 __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
 {
-    __shared__ TreeWork work0;
+    __shared__ __attribute__((aligned(16))) TreeWork work0;
     __shared__ TreeWorkD work1;
     __shared__ uint32_t hist[kLCodes + kDCodes + 2];
     __shared__ uint16_t lcode[kLCodes + 2], dcode[kDCodes + 2], blcode[kBLCodes + 1];
     __shared__ uint8_t llen[kLCodes + 2], dlen[kDCodes + 2], bllen[kBLCodes + 1];
     __shared__ uint32_t tmp[4];
-    __shared__ __attribute__((aligned(16))) uint32_t tokbuf[kEmitRound];          // one round of tokens, so that global reads are coalesced and lanes still own runs
-    __shared__ uint32_t obuf[(kEmitRound * 48 + 31 + 31) / 32 + 1];               // the round's bits (a token is 48 bits at most), assembled with LDS atomics
+    // token emission works in the LDS of the literal/length tree's workspace (idle by then): one round of tokens, so that global reads are coalesced
+    // and lanes still own runs, and the round's bits (a token is 48 bits at most), assembled with LDS atomics.  Sixteen workgroups per CU depend on it (and on 64 registers: eight waves per SIMD in the launch bounds).
+    constexpr uint32_t kObufWords = (kEmitRound * 48 + 31 + 31) / 32 + 1;
+    static_assert(sizeof(TreeWork) >= (kEmitRound + kObufWords) * 4 && alignof(TreeWork) >= 8, "emit buffers live in the tree workspace");
+    uint32_t *tokbuf = reinterpret_cast<uint32_t *>(&work0), *obuf = tokbuf + kEmitRound;
     __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
     __shared__ uint64_t sh_bitpos;
 
@@ -312,7 +315,6 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
     if (tid == 0) sh_bitpos = 0;
-    for (uint32_t i = tid; i < sizeof(obuf) / 4; i += kThreads) obuf[i] = 0;
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
@@ -411,6 +413,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             // Rounds of kEmitRound tokens (the end-of-block code is the token behind the last): read coalesced into LDS, kEmitPer consecutive ones
             // per lane sized and coded once, a prefix scan for the bit offsets, the bits put together in LDS (ds_or), the round's words stored
             // coalesced -- the first and the last, shared with what lies in front and behind, by atomic OR (the slot is zero-initialised).
+            for (uint32_t i = tid; i < kObufWords; i += kThreads) obuf[i] = 0; // (the first round's barrier stands between this and the first bits)
             for (uint32_t r0 = 0; r0 <= nt; r0 += kEmitRound) {
                 uint32_t tv[kEmitPer];
 #pragma unroll
