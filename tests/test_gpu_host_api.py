@@ -206,3 +206,37 @@ def test_level0_block_structure():
             want = O.deflate_stream(b"", 0)[:2] + b"".join(O.deflate_chunk(data[k * 65536:(k + 1) * 65536], 0, False) for k in range(nch)) + \
                 O.deflate_chunk(b"", 0, True) + O.adler32(data).to_bytes(4, "big")
             assert z2 == want, n
+
+
+def test_host_buffers_in_batches_with_copies_under_the_kernels():
+    """zgpu_deflate_host over more than one batch (ZGPU_BATCH_CHUNKS makes batches small): the input arrives batch by batch on the copy stream and a
+    second host thread takes finished batches' bytes home while later ones are compressed.  The stream must be the one-batch device stream."""
+    import hashlib
+    import os
+    import torch
+    import zlib_amd
+    from zlib_amd import gpu
+    e = zlib_amd.Engine(0)
+    n = 8192 + 700  # more than the 8192 chunks below which the host entry point does not bother to overlap
+    src = torch.empty(n * 65536, dtype=torch.uint8, device="cuda")
+    e.corpus_fill_device(0, 0x5EED5117, 3, n, src.data_ptr())
+    cap = e.L.zgpu_deflate_bound(n * 65536, 65536)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    res = e.deflate_device(src.data_ptr(), n * 65536, 6, dst.data_ptr(), cap)
+    want = hashlib.sha256(dst[: res.out_bytes].cpu().numpy().tobytes()).hexdigest()
+    host = src.cpu().numpy()
+    old = os.environ.get("ZGPU_BATCH_CHUNKS")
+    try:
+        for batch in ("1500", None):
+            if batch is None:
+                os.environ.pop("ZGPU_BATCH_CHUNKS", None)
+            else:
+                os.environ["ZGPU_BATCH_CHUNKS"] = batch
+            z = e.deflate_host(host, 6)
+            assert len(z) == res.out_bytes and hashlib.sha256(z).hexdigest() == want, batch
+    finally:
+        if old is None:
+            os.environ.pop("ZGPU_BATCH_CHUNKS", None)
+        else:
+            os.environ["ZGPU_BATCH_CHUNKS"] = old
+    e.close()

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace zgpu {
@@ -39,6 +41,9 @@ struct zgpu_engine {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr; // H2D of the *_host entry points: the next batch's input moves while this batch's kernels run
     std::vector<hipEvent_t> copy_ev;
+    hipStream_t d2h_stream = nullptr;  // D2H of zgpu_deflate_host: finished batches' bytes go home while later batches are compressed (a second host thread)
+    std::vector<hipEvent_t> done_ev;
+    uint64_t *pin_tot = nullptr;       // pinned: out_total behind every batch
     char err[512] = {0};
     // deflate workspace, sized for `batch_cap` chunks
     uint32_t batch_cap = 0;
@@ -167,7 +172,8 @@ static void zlib_header(int level, int strategy, uint8_t hdr[2]) // qcsrc/deflat
 // copy stream right before the batch's kernels are queued, so the copy of batch k+1 runs under the kernels of batch k.
 static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_seg, uint64_t nseg,
                           const zgpu_deflate_params *p, uint8_t *d_out, uint64_t out_cap, uint64_t *d_chunk_offsets,
-                          zgpu_deflate_result *res, hipStream_t st, uint32_t skip0 = 0, const uint8_t *h_src = nullptr)
+                          zgpu_deflate_result *res, hipStream_t st, uint32_t skip0 = 0, const uint8_t *h_src = nullptr, uint8_t *h_dst = nullptr,
+                          uint64_t h_cap = 0, uint64_t *h_copied = nullptr)
 {
     if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     if (p->level < 1 || p->level > 9) return fail(e, ZGPU_STREAM_ERROR, "level must be 1..9");
@@ -214,7 +220,10 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // chunks in flight to fill 256 CUs, so batches are as large as device memory allows (~1 MiB of workspace per chunk).
     uint32_t batch_max = env_u32("ZGPU_BATCH_CHUNKS", 65536); // (small values are for tests: several launches per call)
     if (batch_max == 0) batch_max = 1;
-    if (h_src && batch_max > 4096) batch_max = 4096; // host input: 256 MiB per batch, so that copies and kernels take turns often enough to overlap
+    // host input: the copy of batch k+1 runs under the kernels of batch k.  Batches must stay large: the block-construction and sort kernels are
+    // latency-bound and need every workgroup slot of the chip filled several times over (2048 chunks per launch: 2.2x the time per byte of
+    // 65536, rocprofv3 timeline of scripts/host_trace.py); the copy moves 57 GB/s and is over long before the kernels are
+    if (h_src && batch_max > 8192) batch_max = 8192;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
@@ -250,6 +259,39 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 10, hipMemcpyHostToDevice, st));
     }
 
+    // h_dst: what the batches so far have produced goes to the caller's buffer while the next ones are compressed.  Copies to pageable memory
+    // hold the calling thread, so they are a second thread's: it waits for batch k's event, reads the stream length behind it (pinned)
+    // and copies the new bytes on a stream of its own.
+    const size_t nbatches = (size_t)((nchunks + batch - 1) / batch);
+    std::thread homer;
+    std::atomic<size_t> issued{0};
+    std::atomic<int> homer_rc{0};
+    uint64_t homed = 0;
+    const bool home = h_dst && h_src && nbatches > 1 && nbatches <= 4096;
+    struct HomeGuard { // (the checks below return from the middle of the loop: the thread must not outlive the call)
+        std::thread &t; std::atomic<size_t> &n;
+        ~HomeGuard() { if (t.joinable()) { n.store((size_t)-1); t.join(); } }
+    } home_guard{homer, issued};
+    if (home) {
+        if (!e->pin_tot) ZGPU_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&e->pin_tot), 4096 * sizeof(uint64_t), hipHostMallocDefault));
+        if (!e->d2h_stream) ZGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+        while (e->done_ev.size() < nbatches) { hipEvent_t ev; ZGPU_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); e->done_ev.push_back(ev); }
+        homer = std::thread([&, nbatches]() {
+            if (hipSetDevice(e->device) != hipSuccess) { homer_rc = 1; return; }
+            for (size_t k = 0; k < nbatches; k++) {
+                while (issued.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+                if (issued.load() == (size_t)-1) return; // the call gave up
+                if (hipEventSynchronize(e->done_ev[k]) != hipSuccess) { homer_rc = 1; return; }
+                uint64_t upto = e->pin_tot[k];
+                if (upto > h_cap) upto = h_cap;
+                if (upto > homed) {
+                    if (hipMemcpyAsync(h_dst + homed, d_out + homed, upto - homed, hipMemcpyDeviceToHost, e->d2h_stream) != hipSuccess ||
+                        hipStreamSynchronize(e->d2h_stream) != hipSuccess) { homer_rc = 1; return; }
+                    homed = upto;
+                }
+            }
+        });
+    }
     size_t nbatch = 0;
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch, nbatch++) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
@@ -281,15 +323,25 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st, gz || (p->flags & ZGPU_F_CRC32));
             launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);
         }
-        ZGPU_HIP_CHECK(hipGetLastError());
+        if (home) {
+            hipError_t he = hipMemcpyAsync(&e->pin_tot[nbatch], e->run, sizeof(uint64_t), hipMemcpyDeviceToHost, st); // RunState::out_total
+            if (he == hipSuccess) he = hipEventRecord(e->done_ev[nbatch], st);
+            if (he != hipSuccess) { issued.store((size_t)-1); homer.join(); return zgpu::fail_hip(e, he, "batch hand-over", __FILE__, __LINE__); }
+            issued.store(nbatch + 1, std::memory_order_release);
+        }
+        {
+            const hipError_t he = hipGetLastError();
+            if (he != hipSuccess) { if (home) { issued.store((size_t)-1); homer.join(); } return zgpu::fail_hip(e, he, "kernel launch", __FILE__, __LINE__); }
+        }
     }
+    if (home) { homer.join(); if (homer_rc.load()) return fail(e, ZGPU_ERRNO, "copy of finished batches to the host failed"); if (h_copied) *h_copied = homed; }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
     if (check_sort) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault, lz_sorted_fault_word(e->par_ws), 4, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     collect_spans(e);
     if (sort_fault) { // the LDS did not serve an atomic's lanes in lane order: redo the call with the sort that does not rely on it
         e->exact_sort = 1;
-        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st, skip0, h_src);
+        return deflate_device(e, d_in, in_bytes, d_seg, nseg, p, d_out, out_cap, d_chunk_offsets, res, st, skip0, h_src, h_dst, h_cap, h_copied);
     }
     if (rs.overflow || (tail_bytes && out_cap < rs.out_total + tail_bytes)) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     const uint32_t adler = rs.adler_a | (rs.adler_b << 16);
@@ -376,6 +428,9 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
+    for (auto ev : e->done_ev) hipEventDestroy(ev);
+    if (e->d2h_stream) hipStreamDestroy(e->d2h_stream);
+    if (e->pin_tot) hipHostFree(e->pin_tot);
     hipStreamDestroy(e->copy_stream);
     hipStreamDestroy(e->stream);
     delete e;
@@ -435,12 +490,14 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
     if (rc) return rc;
     // (the copy stream must not run ahead of the previous call's kernels, which may still read the staging buffer: it starts behind them)
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    const bool overlap = in_bytes > (uint64_t)4096 * chunk_size; // (more than one batch: otherwise there is nothing to overlap the copy with)
+    const bool overlap = in_bytes > (uint64_t)8192 * chunk_size; // (more than one batch: otherwise there is nothing to overlap the copy with)
     if (!overlap && in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
-    rc = deflate_device(e, e->stage_in, in_bytes, nullptr, 0, p, e->stage_out, bound, nullptr, res, e->stream, 0, overlap ? static_cast<const uint8_t *>(in) : nullptr);
+    uint64_t homed = 0; // bytes of the stream that went to `out` while later batches were compressed
+    rc = deflate_device(e, e->stage_in, in_bytes, nullptr, 0, p, e->stage_out, bound, nullptr, res, e->stream, 0, overlap ? static_cast<const uint8_t *>(in) : nullptr,
+                        overlap ? static_cast<uint8_t *>(out) : nullptr, out_cap, &homed);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
-    ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (res->out_bytes > homed) ZGPU_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(out) + homed, e->stage_out + homed, res->out_bytes - homed, hipMemcpyDeviceToHost, e->stream));
     if (chunk_offsets) ZGPU_HIP_CHECK(hipMemcpyAsync(chunk_offsets, e->offsets, (res->nchunks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     return ZGPU_OK;
