@@ -177,6 +177,9 @@ int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes,
  * the chain of pieces is checked and the unknowns filled in afterwards (zgpu_inflate.hip, spec_*).  A stream whose pieces do
  * not chain -- damaged, cut short, or one false block start -- goes through the one-workgroup decoder and gets its verdict.
  * Diagnostics: how many streams this process decoded in pieces / sent to the one-workgroup decoder. */
+/* Test hook: the next launch of the fast position sort reports that its self-check failed (the LDS did not serve an atomic's lanes in
+ * lane order), so that the engine's fallback -- redo the call with the ballot-ranked sort, and keep to it -- can be exercised. */
+void zgpu_debug_inject_sort_fault(void);
 uint64_t zgpu_inflate_spec_count(int which); /* 0: decoded in pieces, 1: one-workgroup decodes */
 const char *zgpu_inflate_message(uint32_t index);
 /* Preset dictionary of the inflate calls that follow (inflateSetDictionary, qcsrc/inflate.c:1200-1236): the first segment of a

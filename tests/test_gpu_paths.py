@@ -1,7 +1,7 @@
 """GPU: the alternative kernel paths of the levels 4-9 pipeline must produce the same bytes as the default one.
 
   ZGPU_SORT=1            sort_kernel (ballots only) instead of sort3_kernel (ordered LDS atomics + self-check)
-  ZGPU_SORT_FAULT_TEST=1 sort3's self-check reports a fault -> the engine redoes the call with sort_kernel
+  ZTEST_SORT_FAULT=1 (read by the child script, which calls zgpu_debug_inject_sort_fault): sort3's self-check reports a fault -> the engine redoes the call with sort_kernel
   ZGPU_PARSE=1           parse_kernel (the reference loop, one lane per chunk) instead of parse2_kernel
 
 The switches are read once per process, so every variant runs in a child process (one at a time) and prints the
@@ -24,6 +24,10 @@ sys.path.insert(0, %r)
 from oracle import cases, corpus_py as CP
 import zlib_amd
 e = zlib_amd.Engine(0)
+import os
+if os.environ.get("ZTEST_SORT_FAULT"):
+    e.L.zgpu_debug_inject_sort_fault.restype = None
+    e.L.zgpu_debug_inject_sort_fault()
 out = {}
 inputs = {
     "corpus0": CP.chunks(0, 0, 24).tobytes(),
@@ -41,7 +45,7 @@ print("DIGESTS " + json.dumps(out, sort_keys=True))
 
 def run_variant(env_extra):
     env = dict(os.environ)
-    for k in ("ZGPU_SORT", "ZGPU_SORT_FAULT_TEST", "ZGPU_PARSE", "ZGPU_BATCH_CHUNKS"):
+    for k in ("ZGPU_SORT", "ZTEST_SORT_FAULT", "ZGPU_PARSE", "ZGPU_BATCH_CHUNKS"):
         env.pop(k, None)
     env.update(env_extra)
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=900)
@@ -58,6 +62,6 @@ def test_alternative_paths_agree():
     assert base["corpus0/6"] == hashlib.sha256(O.deflate_stream(data, 6, 65536)).hexdigest()
     assert base["zeros/9"] == hashlib.sha256(O.deflate_stream(bytes(3 * 65536 + 5), 9, 65536)).hexdigest()
     # ... and a batch size of 7 chunks: every multi-chunk input above then takes several launches of every stage
-    for env in ({"ZGPU_SORT": "1"}, {"ZGPU_SORT_FAULT_TEST": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}, {"ZGPU_BATCH_CHUNKS": "7"}):
+    for env in ({"ZGPU_SORT": "1"}, {"ZTEST_SORT_FAULT": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}, {"ZGPU_BATCH_CHUNKS": "7"}):
         got = run_variant(env)
         assert got == base, "variant %r differs: %s" % (env, [k for k in base if got.get(k) != base[k]])

@@ -68,3 +68,29 @@ def test_adler_join_matches_oracle():
     a, b = cases.make("rand", 70001, 1), cases.make("text", 12345, 2)
     assert shard.adler_join(O.adler32(a), O.adler32(b), len(b)) == O.adler32(a + b)
     assert shard.adler_join(1, O.adler32(b), len(b)) == O.adler32(b)
+
+
+def test_inflate_partition_decodes_disjoint_ranges_of_one_stream():
+    """SURVEY.md 8e, last row: every rank decodes a contiguous chunk range of ONE stream from the compressor's chunk table; the ranges'
+    outputs, side by side, are the input (decoded here by the CPU oracle, one rank after the other: there is nothing to exchange)."""
+    from zlib_amd import shard
+    data = cases.make("mix", 65536 * 9 + 4321, 23)
+    nchunks = (len(data) + 65535) // 65536
+    segs = [O.deflate_chunk(data[k * 65536:(k + 1) * 65536], 6, k == nchunks - 1) for k in range(nchunks)]
+    body = b"".join(segs)
+    offsets = [0]
+    for s in segs:
+        offsets.append(offsets[-1] + len(s))
+    for world in (1, 2, 3, 4, 16):
+        out = bytearray(len(data))
+        covered = 0
+        for rank in range(world):
+            lo, hi, c0, c1, o0, table = shard.inflate_partition(offsets, 65536, rank, world)
+            assert table[0] == 0 and table[-1] == c1 - c0 and len(table) == hi - lo + 1
+            piece = body[c0:c1]
+            for k in range(hi - lo):
+                rc, dec, used, msg = O.inflate_raw(piece[table[k]:table[k + 1]], 65536)
+                assert rc == 1 if lo + k == nchunks - 1 else rc in (0, -5), (rc, msg)  # (a chunk that is not the last ends with a flush marker: the decoder wants more)
+                out[o0 + k * 65536: o0 + k * 65536 + len(dec)] = dec
+                covered += len(dec)
+        assert covered == len(data) and bytes(out) == data, world

@@ -24,6 +24,10 @@
 #include <cstdlib>
 #include "../../include/zamd_gpu.h"
 
+#include <atomic>
+static std::atomic<int> g_inject_sort_fault{0};
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_inject_sort_fault(void) { g_inject_sort_fault.store(1); }
+
 namespace zgpu {
 
 void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
@@ -1013,9 +1017,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     }
     else {
         hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir);
-        static int fault_test = -1; // tests/test_gpu_deflate.py: exercise the engine's fallback without a real fault
-        if (fault_test < 0) fault_test = getenv("ZGPU_SORT_FAULT_TEST") ? 1 : 0;
-        if (fault_test) hipMemsetAsync(fault, 1, 4, st);
+        if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st); // zgpu_debug_inject_sort_fault(): exercise the engine's fallback without a real fault
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);

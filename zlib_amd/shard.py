@@ -25,6 +25,17 @@ def chunk_range(nchunks: int, rank: int, world: int):
     return lo, hi
 
 
+def inflate_partition(offsets, chunk_size: int, rank: int, world: int):
+    """Multi-GPU inflate (last row): the compressor's chunk table cuts the stream wherever a chunk ends, so rank r decodes the
+    contiguous chunk range chunk_range(M, r, world) -- compressed bytes [offsets[lo], offsets[hi]) -- into the output range
+    [lo * chunk_size, hi * chunk_size) (the last chunk may be short): disjoint ranges, no collective.  Returns
+    (lo, hi, first compressed byte, behind the last compressed byte, first output byte, the rank's table re-based to 0)."""
+    m = len(offsets) - 1
+    lo, hi = chunk_range(m, rank, world)
+    base = int(offsets[lo])
+    return lo, hi, base, int(offsets[hi]), lo * chunk_size, [int(o) - base for o in offsets[lo:hi + 1]]
+
+
 def adler_join(x: int, y: int, len_y: int) -> int:
     ax, bx, ay, by = x & 0xFFFF, x >> 16, y & 0xFFFF, y >> 16
     a = (ax + ay + ADLER_BASE - 1) % ADLER_BASE
