@@ -281,16 +281,43 @@ template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b
     const uint32_t ndist = peek(b, 5) + 1; drop(b, 5);
     const uint32_t ncode = peek(b, 4) + 4; drop(b, 4);
     if (nlen > 286 || ndist > 30) return kMsgTooMany;
-    wave_sync();
-    for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-    wave_sync();
-    for (uint32_t i = 0; i < ncode; i++) { refill(b, L.stage); const uint32_t v = peek(b, 3); drop(b, 3); if (lane == 0) L.lens[kClOrder[i]] = (uint16_t)v; }
-    wave_sync();
-    // the code-length code reuses the distance table storage (7-bit codes fit its 9-bit index)
-    if (build_table(L, L.lens, 19, 0, 7, L.dtab, L.dsym, L.dcount, lane)) return kMsgCodeLens;
-    wave_sync();
-    // the 128 entries of the code-length code's table live in two registers per lane from here on: a look-up is a v_readlane, not a round trip to LDS
-    const uint32_t cl0 = L.dtab[lane], cl1 = L.dtab[64 + lane];
+    // The code-length code (19 symbols, codes of at most 7 bits) is built in registers: lane s holds the length of symbol s, the canonical codes come
+    // from ballots, and the 128-entry decoding table lives in two registers per lane (entry `lane` and entry `64 + lane`: a look-up is a
+    // v_readlane, not a round trip to LDS).  inflate_table's rules for this code (inftrees.c:106-138): over-subscribed or incomplete is an error.
+    uint64_t y;
+    {
+        refill(b, L.stage);
+        const uint32_t n0 = ncode < 10 ? ncode : 10;
+        const uint64_t lo = peek(b, 3 * n0); drop(b, 3 * n0);
+        refill(b, L.stage);
+        const uint32_t n1 = ncode - n0;
+        const uint64_t hi = n1 ? peek(b, 3 * n1) : 0u; drop(b, 3 * n1);
+        y = lo | (hi << 30);
+    }
+    // where symbol s stands in the order the lengths are sent in (16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15): five bits each
+    constexpr uint64_t kInvLo = 3ull | (17ull << 5) | (15ull << 10) | (13ull << 15) | (11ull << 20) | (9ull << 25) | (7ull << 30) | (5ull << 35) | (4ull << 40) | (6ull << 45) | (8ull << 50) | (10ull << 55);
+    constexpr uint64_t kInvHi = 12ull | (14ull << 5) | (16ull << 10) | (18ull << 15) | (0ull << 20) | (1ull << 25) | (2ull << 30);
+    const uint32_t where = lane < 12 ? (uint32_t)(kInvLo >> (5 * lane)) & 31u : lane < 19 ? (uint32_t)(kInvHi >> (5 * (lane - 12))) & 31u : 31u;
+    const uint32_t cl_len = where < ncode ? (uint32_t)(y >> (3 * where)) & 7u : 0u;
+    uint32_t cl_first[8], cl_rank = 0, kraft = 0, code = 0, prev_count = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 7; l++) {
+        const uint64_t m = __ballot(cl_len == l);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m), below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        code = (code + prev_count) << 1; cl_first[l] = code; prev_count = cnt;
+        kraft += cnt * (128u >> l);
+        if (cl_len == l) cl_rank = cl_first[l] + below;
+    }
+    if (kraft != 128u && kraft != 0u) return kMsgCodeLens; // (no code at all: every look-up below fails, as the reference's empty table does)
+    const uint32_t cl_rev = cl_len ? __brev(cl_rank) >> (32 - cl_len) : 0u;
+    uint32_t cl0 = 0, cl1 = 0;
+    for (uint32_t sy = 0; sy < 19; sy++) {
+        const uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)cl_len, (int)sy);
+        if (!ls) continue;
+        const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)cl_rev, (int)sy), mk = (1u << ls) - 1, e = (sy << 8) | ls;
+        if ((lane & mk) == rs) cl0 = e;
+        if (((lane + 64) & mk) == rs) cl1 = e;
+    }
     wave_sync();
     for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
     uint32_t have = 0, prev = 0;
