@@ -202,10 +202,14 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         static int auto_env = -1; // ZGPU_LZ_DEFAULT=3: A/B runs of the all-position search
         if (auto_env < 0) { const char *v = getenv("ZGPU_LZ_DEFAULT"); auto_env = v ? atoi(v) : 0; }
         impl = (cfg.slow && lz_parallel_available()) ? ((walk_ok && auto_env != ZGPU_LZ_SORTED) ? ZGPU_LZ_WALK : ZGPU_LZ_SORTED) : ZGPU_LZ_SERIAL;
+        // levels 1-3: deflate_fast on the sorted buckets (fast_kernel, zgpu_lz_sorted.hip); the head[]/prev[] loop stays for the two strategies that
+        // are special cases of its search, for a chunk behind a preset dictionary, and as the cross-check (ZGPU_LZ_SERIAL, ZGPU_LZ_DEFAULT=1)
+        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env != ZGPU_LZ_SERIAL) impl = ZGPU_LZ_FAST;
     }
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
-    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_WALK) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
+    if (impl == ZGPU_LZ_FAST && (cfg.slow || !walk_ok || skip0 || !lz_parallel_available())) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_FAST serves levels 1..3, not Z_HUFFMAN_ONLY / Z_RLE, no dictionary chunk");
+    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_FAST) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
     if (impl == ZGPU_LZ_WALK && !walk_ok) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_WALK does not serve Z_HUFFMAN_ONLY / Z_RLE");
     if (skip0) { // a preset dictionary in front of the one chunk: the lane-per-chunk loop is the implementation that starts mid-window
@@ -250,7 +254,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && !e->exact_sort;
+    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST) && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, p->strategy, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
@@ -308,7 +312,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK);
+            if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST)
+                launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : 0);
             else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {

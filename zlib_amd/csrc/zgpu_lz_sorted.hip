@@ -995,8 +995,125 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
     }
 }
 
+// ======================================================================================================================================
+// Levels 1-3 -- deflate_fast (deflate.c:1448-1546) on the sorted buckets.
+// deflate_fast leaves the positions inside a match longer than max_insert_length out of the hash chains, so its chains depend on its parse and
+// the walkers above (whose state is the position alone) do not apply: one lane runs one chunk's loop (as zgpu_lz_serial.hip does).  What changes is
+// what a step costs.  With head[]/prev[] every POSITION is a chain of dependent trips to memory (read head, write head and prev; then the search).
+// Here the chain of p is its bucket predecessors S[idx-1], S[idx-2], ... (idx, rank = ir[p]) that carry a flag byte G[idx'] = "in the chains";
+// inserting a position is one byte store nobody waits for, and only a TOKEN costs dependent trips: ir, then eight predecessors with their flags,
+// then the candidates' bytes -- 11 600 tokens per chunk at level 1 against 65 536 positions.
+// The window slide, NIL, MAX_DIST, nice_match and the chain budget are longest_match's (deflate.c:1027-1168), as in SerialLz::longest.
+// ======================================================================================================================================
+struct __attribute__((packed, aligned(1))) U32f { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U64f { uint64_t v; };
+constexpr uint32_t kGPad = 32, kGStride = kChunkMax + 2 * kGPad; // flag bytes per chunk, room in front for the group reads
+
+__global__ void __launch_bounds__(64) fast_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all, uint8_t *G_all,
+                                                   uint32_t *__restrict__ tokens, ChunkMeta *meta, uint32_t lanes)
+{
+    if (threadIdx.x >= lanes) return;
+    const uint32_t c = blockIdx.x * lanes + threadIdx.x;
+    if (c >= g.nchunks) return;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *in = g.in + lo;
+    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
+    const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
+    uint8_t *G = G_all + (size_t)c * kGStride + kGPad;
+    uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t base = chunk_base(g, c);
+    uint32_t off = 0, ntok = 0, blk_tok0 = 0, nblk = 0, nostore = 0, block_start = 0;
+    auto cut_block = [&](uint32_t p_end) {
+        if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // buf == NULL, deflate.c:1365-1367
+        nblk++; blk_tok0 = ntok; block_start = p_end;
+    };
+    const uint32_t room = 2 * kWSize - base;
+    uint32_t buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
+    uint32_t p = 0;
+    for (;;) {
+        if (buffered - p < kMinLookahead) { // fill_window: the slide (deflate.c:1293), then the rest of the input
+            if ((int)(p + base) - (int)off >= (int)(kWSize + kMaxDist)) off += kWSize;
+            buffered = n;
+            if (n == p) break;
+        }
+        const uint32_t look = n - p;
+        uint32_t match_len = kMinMatch - 1, mstart = 0;
+        if (look >= kMinMatch) {
+            const uint32_t iv = ir[p], idx = iv & 0xffffu, rank = iv >> 16;
+            // the eight bytes at p (zeros behind the chunk's end, as in the reference's fresh window)
+            uint64_t scan8;
+            if (p + 8 <= n) scan8 = reinterpret_cast<const U64f *>(in + p)->v;
+            else { scan8 = 0; for (uint32_t k = 0; k < look; k++) scan8 |= (uint64_t)in[p + k] << (8 * k); }
+            const int w = (int)(p + base) - (int)off, limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+            const uint32_t cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
+            uint32_t chain = cfg.chain, best = kMinMatch - 1;
+            bool first = true, over = false;
+            for (uint32_t j0 = 1; j0 <= rank && !over; j0 += 8) { // predecessors idx-j0 .. idx-j0-7, nearest first
+                const int at = (int)idx - (int)j0 - 7;
+                const uint4 sv = reinterpret_cast<const U128u *>(S + (at < -(int)kSPad ? -(int)kSPad : at))->v;
+                const uint64_t fl = reinterpret_cast<const U64f *>(G + at)->v;
+                const int shift = at < -(int)kSPad ? -(int)kSPad - at : 0; // (a clamped read: the entries sit `shift` slots higher; j beyond rank is never looked at)
+#pragma unroll
+                for (uint32_t t = 0; t < 8; t++) {
+                    if (over || j0 + t > rank) break;
+                    const uint32_t slot = 7 - t; // the nearest predecessor is the highest address
+                    if (!((fl >> (8 * slot)) & 1u)) continue;
+                    const int es = (int)slot - shift;
+                    const uint32_t wd = es >= 6 ? sv.w : es >= 4 ? sv.z : es >= 2 ? sv.y : sv.x;
+                    const uint32_t q = (es & 1) ? wd >> 16 : wd & 0xffffu;
+                    const int wq = (int)(q + base) - (int)off;
+                    if (wq <= 0) { over = true; break; }                                     // NIL, or gone with the slide
+                    if (first) { if ((uint32_t)(w - wq) > kMaxDist) { over = true; break; } first = false; } // hash_head out of reach: no search (deflate.c:1481)
+                    else if (wq <= limit) { over = true; break; }                            // deflate.c:1163
+                    // the comparison (quick reject on the byte that would extend the best so far, deflate.c:1121-1124, when eight bytes do not say it)
+                    const uint8_t *m = in + q;
+                    if (best < cap && (best < 8 || m[best] == in[p + best])) {
+                        uint32_t l;
+                        uint64_t x0 = 1; // (q < p: the candidate's eight bytes lie inside the chunk whenever those at p do)
+                        if (p + 8 <= n) x0 = reinterpret_cast<const U64f *>(m)->v ^ scan8;
+                        else { l = 0; while (l < cap && m[l] == in[p + l]) l++; goto compared; }
+                        if (x0) l = (uint32_t)__builtin_ctzll(x0) >> 3;
+                        else {
+                            l = 8;
+                            while (l + 8 <= cap) {
+                                const uint64_t x = reinterpret_cast<const U64f *>(m + l)->v ^ reinterpret_cast<const U64f *>(in + p + l)->v;
+                                if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; goto compared; }
+                                l += 8;
+                            }
+                            while (l < cap && m[l] == in[p + l]) l++;
+                        }
+                    compared:
+                        if (l > cap) l = cap;
+                        if (l > best) { mstart = q; best = l; if (l >= nice) { over = true; break; } }
+                    }
+                    if (--chain == 0) { over = true; break; }
+                }
+            }
+            if (!first) match_len = best <= look ? best : look; // a search took place (deflate.c:1166-1167)
+            G[idx] = 1; // INSERT_STRING(strstart)
+        }
+        bool cut;
+        if (match_len >= kMinMatch) {
+            tok[ntok++] = tok_match(p - mstart, match_len - kMinMatch);
+            cut = ntok - blk_tok0 == kBlockTokens;
+            if (match_len <= cfg.lazy && look - match_len >= kMinMatch) // max_insert_length (h/deflate.h:176): the strings inside a short match go in
+                for (uint32_t k = 1; k < match_len; k++) G[ir[p + k] & 0xffffu] = 1;
+            p += match_len;
+        } else {
+            tok[ntok++] = tok_lit(in[p]);
+            cut = ntok - blk_tok0 == kBlockTokens;
+            p++;
+        }
+        if (cut) cut_block(p);
+    }
+    cut_block(p); // the final block (its emission happens in the Huffman stage)
+    meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
+}
+
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
 // `walk`: parse-driven search (walk_kernel + the lite parse) instead of the all-position search (match3_kernel + parse2_kernel)
+// `walk` 2: levels 1-3, deflate_fast on the sorted buckets (fast_kernel)
 void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk)
 {
     uint8_t *w = static_cast<uint8_t *>(workspace);
@@ -1021,6 +1138,17 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
+    if (walk == 2) { // the records' memory holds the flag bytes
+        uint8_t *G = reinterpret_cast<uint8_t *>(recs);
+        hipMemsetAsync(G, 0, nch * kGStride, st);
+        static int forced = -1; // chunks per wave (ZGPU_FAST_LANES): a wave's step takes as long as its slowest lane's memory access
+        if (forced < 0) { const char *v = getenv("ZGPU_FAST_LANES"); forced = v ? atoi(v) : 0; if (forced < 0 || forced > 64) forced = 0; }
+        uint32_t lanes = (uint32_t)forced;
+        if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
+        hipLaunchKernelGGL(fast_kernel, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, S, ir, G, tokens, meta, lanes);
+        prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+        return;
+    }
     if (walk) { // the records' memory holds the walkers' output: gm (u32 per position), then the bitmaps gs (2048 words per chunk)
         uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
         static int fuse = -1; // ZGPU_WALK_FUSE=0: the rest of the parse as a kernel of its own (A/B runs)
