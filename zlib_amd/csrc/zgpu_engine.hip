@@ -202,9 +202,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         static int auto_env = -1; // ZGPU_LZ_DEFAULT=3: A/B runs of the all-position search
         if (auto_env < 0) { const char *v = getenv("ZGPU_LZ_DEFAULT"); auto_env = v ? atoi(v) : 0; }
         impl = (cfg.slow && lz_parallel_available()) ? ((walk_ok && auto_env != ZGPU_LZ_SORTED) ? ZGPU_LZ_WALK : ZGPU_LZ_SORTED) : ZGPU_LZ_SERIAL;
-        // levels 1-3: deflate_fast on the sorted buckets (fast_kernel, zgpu_lz_sorted.hip); the head[]/prev[] loop stays for the two strategies that
-        // are special cases of its search, for a chunk behind a preset dictionary, and as the cross-check (ZGPU_LZ_SERIAL, ZGPU_LZ_DEFAULT=1)
-        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env != ZGPU_LZ_SERIAL) impl = ZGPU_LZ_FAST;
+        // levels 1-3: the head[]/prev[] loop.  deflate_fast on the sorted buckets (ZGPU_LZ_FAST, fast_kernel in zgpu_lz_sorted.hip) is a second
+        // implementation for the parity tests and for ZGPU_LZ_DEFAULT=5: it asks memory four times less often and is no faster
+        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env == ZGPU_LZ_FAST) impl = ZGPU_LZ_FAST;
     }
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");

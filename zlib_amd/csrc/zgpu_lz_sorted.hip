@@ -1005,24 +1005,49 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
 // then the candidates' bytes -- 11 600 tokens per chunk at level 1 against 65 536 positions.
 // The window slide, NIL, MAX_DIST, nice_match and the chain budget are longest_match's (deflate.c:1027-1168), as in SerialLz::longest.
 // ======================================================================================================================================
-struct __attribute__((packed, aligned(1))) U32f { uint32_t v; };
-struct __attribute__((packed, aligned(1))) U64f { uint64_t v; };
+struct __attribute__((packed, aligned(1))) U128b { uint4 v; };
 constexpr uint32_t kGPad = 32, kGStride = kChunkMax + 2 * kGPad; // flag bytes per chunk, room in front for the group reads
+enum : uint32_t { F_IR = 0, F_GROUP, F_CAND, F_EXT, F_DONE };
 
+// index of the first byte in which two 16-byte strings differ (16: none)
+__device__ inline uint32_t first_diff16(uint4 a, uint4 b)
+{
+    const uint64_t x0 = (((uint64_t)(a.y ^ b.y)) << 32) | (a.x ^ b.x), x1 = (((uint64_t)(a.w ^ b.w)) << 32) | (a.z ^ b.z);
+    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8 + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u;
+}
+
+// 16 bytes at in + o where a 16-byte read would run past the end of the buffer (zeros behind it: lengths are capped, they never count)
+__device__ __noinline__ uint4 tail16(const uint8_t *in, uint32_t o, uint64_t safe_end)
+{
+    uint32_t v[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16 && (uint64_t)o + k < safe_end; k++) v[k >> 2] |= (uint32_t)in[o + k] << (8 * (k & 3));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// One lane per chunk, and the lanes of a wave in step: a lane whose loop waits for memory would hold up the 63 others wherever their loops stand
+// (one instruction stream), so the loop is turned inside out.  Every lane is in one of four states; a round of the wave lets every lane ask for
+// up to five 16-byte pieces of memory, waits ONCE for all of them, and lets every lane take its state one step further:
+//   F_IR     ir[p..p+7] and the 16 bytes at p (after a long match; the others carry them over)      -> the search is set up
+//   F_GROUP  eight bucket predecessors and their flag bytes (+ ir and bytes for a fresh token)        -> up to four candidates picked
+//   F_CAND   16 bytes at each candidate                                                               -> longest_match's bookkeeping, in order
+//   F_EXT    16 more bytes of a candidate that matched all 16, and of the string at p
+// then emits its token, sets the flags of what went into the chains, and starts the next token.  A token costs two to three rounds.
 __global__ void __launch_bounds__(64) fast_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all, uint8_t *G_all,
                                                    uint32_t *__restrict__ tokens, ChunkMeta *meta, uint32_t lanes)
 {
-    if (threadIdx.x >= lanes) return;
     const uint32_t c = blockIdx.x * lanes + threadIdx.x;
-    if (c >= g.nchunks) return;
+    const bool live = threadIdx.x < lanes && c < g.nchunks;
+    const uint32_t cc = live ? c : 0;
     uint64_t lo; uint32_t n;
-    chunk_span(g, c, lo, n);
+    chunk_span(g, cc, lo, n);
     const uint8_t *in = g.in + lo;
-    const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
-    const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
-    uint8_t *G = G_all + (size_t)c * kGStride + kGPad;
-    uint32_t *tok = tokens + (size_t)c * kChunkMax;
-    const uint32_t base = chunk_base(g, c);
+    const uint64_t safe_end = g.in_bytes - lo; // bytes from the chunk's first to the end of the input buffer: what a 16-byte read may touch
+    const uint16_t *S = S_all + (size_t)cc * kSStride + kSPad;
+    const uint32_t *ir = ir_all + (size_t)cc * kChunkMax;
+    uint8_t *G = G_all + (size_t)cc * kGStride + kGPad;
+    uint32_t *tok = tokens + (size_t)cc * kChunkMax;
+    const uint8_t *dummy = reinterpret_cast<const uint8_t *>(S_all); // what a lane reads when it has nothing to ask for (one cached line)
+    const uint32_t base = chunk_base(g, cc);
     uint32_t off = 0, ntok = 0, blk_tok0 = 0, nblk = 0, nostore = 0, block_start = 0;
     auto cut_block = [&](uint32_t p_end) {
         if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // buf == NULL, deflate.c:1365-1367
@@ -1030,85 +1055,144 @@ __global__ void __launch_bounds__(64) fast_kernel(ChunkGeom g, LevelCfg cfg, con
     };
     const uint32_t room = 2 * kWSize - base;
     uint32_t buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
-    uint32_t p = 0;
-    for (;;) {
-        if (buffered - p < kMinLookahead) { // fill_window: the slide (deflate.c:1293), then the rest of the input
+    uint32_t p = 0, st = live ? F_IR : F_DONE;
+    // the loop top of deflate_fast for the token that starts at p: fill_window (the slide, deflate.c:1293), the end of the input
+    auto token_top = [&]() {
+        if (buffered - p < kMinLookahead) {
             if ((int)(p + base) - (int)off >= (int)(kWSize + kMaxDist)) off += kWSize;
             buffered = n;
-            if (n == p) break;
+            if (n == p) { cut_block(p); st = F_DONE; } // the final block (its emission happens in the Huffman stage)
         }
-        const uint32_t look = n - p;
-        uint32_t match_len = kMinMatch - 1, mstart = 0;
-        if (look >= kMinMatch) {
-            const uint32_t iv = ir[p], idx = iv & 0xffffu, rank = iv >> 16;
-            // the eight bytes at p (zeros behind the chunk's end, as in the reference's fresh window)
-            uint64_t scan8;
-            if (p + 8 <= n) scan8 = reinterpret_cast<const U64f *>(in + p)->v;
-            else { scan8 = 0; for (uint32_t k = 0; k < look; k++) scan8 |= (uint64_t)in[p + k] << (8 * k); }
-            const int w = (int)(p + base) - (int)off, limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
-            const uint32_t cap = look < kMaxMatch ? look : kMaxMatch, nice = cfg.nice < look ? cfg.nice : look;
-            uint32_t chain = cfg.chain, best = kMinMatch - 1;
-            bool first = true, over = false;
-            for (uint32_t j0 = 1; j0 <= rank && !over; j0 += 8) { // predecessors idx-j0 .. idx-j0-7, nearest first
-                const int at = (int)idx - (int)j0 - 7;
-                const uint4 sv = reinterpret_cast<const U128u *>(S + (at < -(int)kSPad ? -(int)kSPad : at))->v;
-                const uint64_t fl = reinterpret_cast<const U64f *>(G + at)->v;
-                const int shift = at < -(int)kSPad ? -(int)kSPad - at : 0; // (a clamped read: the entries sit `shift` slots higher; j beyond rank is never looked at)
-#pragma unroll
-                for (uint32_t t = 0; t < 8; t++) {
-                    if (over || j0 + t > rank) break;
-                    const uint32_t slot = 7 - t; // the nearest predecessor is the highest address
-                    if (!((fl >> (8 * slot)) & 1u)) continue;
-                    const int es = (int)slot - shift;
-                    const uint32_t wd = es >= 6 ? sv.w : es >= 4 ? sv.z : es >= 2 ? sv.y : sv.x;
-                    const uint32_t q = (es & 1) ? wd >> 16 : wd & 0xffffu;
-                    const int wq = (int)(q + base) - (int)off;
-                    if (wq <= 0) { over = true; break; }                                     // NIL, or gone with the slide
-                    if (first) { if ((uint32_t)(w - wq) > kMaxDist) { over = true; break; } first = false; } // hash_head out of reach: no search (deflate.c:1481)
-                    else if (wq <= limit) { over = true; break; }                            // deflate.c:1163
-                    // the comparison (quick reject on the byte that would extend the best so far, deflate.c:1121-1124, when eight bytes do not say it)
-                    const uint8_t *m = in + q;
-                    if (best < cap && (best < 8 || m[best] == in[p + best])) {
-                        uint32_t l;
-                        uint64_t x0 = 1; // (q < p: the candidate's eight bytes lie inside the chunk whenever those at p do)
-                        if (p + 8 <= n) x0 = reinterpret_cast<const U64f *>(m)->v ^ scan8;
-                        else { l = 0; while (l < cap && m[l] == in[p + l]) l++; goto compared; }
-                        if (x0) l = (uint32_t)__builtin_ctzll(x0) >> 3;
-                        else {
-                            l = 8;
-                            while (l + 8 <= cap) {
-                                const uint64_t x = reinterpret_cast<const U64f *>(m + l)->v ^ reinterpret_cast<const U64f *>(in + p + l)->v;
-                                if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; goto compared; }
-                                l += 8;
-                            }
-                            while (l < cap && m[l] == in[p + l]) l++;
-                        }
-                    compared:
-                        if (l > cap) l = cap;
-                        if (l > best) { mstart = q; best = l; if (l >= nice) { over = true; break; } }
-                    }
-                    if (--chain == 0) { over = true; break; }
-                }
+    };
+    if (live) token_top();
+    uint32_t irw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint4 scan = make_uint4(0, 0, 0, 0), cb[4] = {scan, scan, scan, scan};
+    bool fresh = false; // F_GROUP: ir and the bytes at p still have to be fetched (the token's idx came from the last token's ir)
+    // the search at p
+    uint32_t idx = 0, rank = 0, j0 = 0, chain = 0, best = 0, mstart = 0, cap = 0, nice = 0, look = 0, ncand = 0, cand[4] = {0, 0, 0, 0}, extl = 0;
+    int w = 0, limit = 0;
+    bool first = true, over = false, lastg = false;
+
+    auto setup_search = [&](uint32_t iv) { // the token at p has at least three bytes
+        idx = iv & 0xffffu; rank = iv >> 16;
+        w = (int)(p + base) - (int)off; limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+        cap = look < kMaxMatch ? look : kMaxMatch; nice = cfg.nice < look ? cfg.nice : look;
+        chain = cfg.chain; best = kMinMatch - 1; first = true; over = false; lastg = false; j0 = 0; ncand = 0;
+    };
+
+    for (;;) {
+        if (__builtin_amdgcn_ballot_w64(st != F_DONE) == 0) break;
+        // ---- what every lane asks for: five 16-byte pieces, by state (kNone: a pointer into the workspace, else an offset into the chunk's bytes) ----
+        constexpr uint32_t kNone = 0xffffffffu;
+        const uint8_t *a0 = dummy, *a1 = dummy, *a2 = dummy, *a3 = dummy;
+        uint32_t o0 = kNone, o1 = kNone, o2 = kNone, o3 = kNone, o4 = kNone;
+        const bool want_ir = st == F_IR || (st == F_GROUP && fresh);
+        if (want_ir) { a2 = reinterpret_cast<const uint8_t *>(ir + p); a3 = reinterpret_cast<const uint8_t *>(ir + p + 4); o4 = p; }
+        if (st == F_GROUP) { const int at = (int)idx - (int)j0 - 8; a0 = reinterpret_cast<const uint8_t *>(S + at); a1 = G + at; } // predecessors idx-j0-8 .. idx-j0-1
+        if (st == F_CAND) { o0 = cand[0]; o1 = ncand > 1 ? cand[1] : kNone; o2 = ncand > 2 ? cand[2] : kNone; o3 = ncand > 3 ? cand[3] : kNone; }
+        if (st == F_EXT) { o0 = cand[0] + extl; o1 = p + extl; }
+        // (a 16-byte read that would run past the input buffer -- the last bytes of the last chunk -- is made byte by byte below)
+        const bool u0 = o0 != kNone && (uint64_t)o0 + 16 > safe_end, u1 = o1 != kNone && (uint64_t)o1 + 16 > safe_end, u2 = o2 != kNone && (uint64_t)o2 + 16 > safe_end,
+                   u3 = o3 != kNone && (uint64_t)o3 + 16 > safe_end, u4 = o4 != kNone && (uint64_t)o4 + 16 > safe_end;
+        if (o0 != kNone && !u0) a0 = in + o0;
+        if (o1 != kNone && !u1) a1 = in + o1;
+        if (o2 != kNone && !u2) a2 = in + o2;
+        if (o3 != kNone && !u3) a3 = in + o3;
+        const uint8_t *a4 = (o4 != kNone && !u4) ? in + o4 : dummy;
+        uint4 r0 = reinterpret_cast<const U128b *>(a0)->v, r1 = reinterpret_cast<const U128b *>(a1)->v, r2 = reinterpret_cast<const U128b *>(a2)->v,
+              r3 = reinterpret_cast<const U128b *>(a3)->v, r4 = reinterpret_cast<const U128b *>(a4)->v;
+        if (__builtin_amdgcn_ballot_w64(u0 || u1 || u2 || u3 || u4)) {
+            if (u0) r0 = tail16(in, o0, safe_end);
+            if (u1) r1 = tail16(in, o1, safe_end);
+            if (u2) r2 = tail16(in, o2, safe_end);
+            if (u3) r3 = tail16(in, o3, safe_end);
+            if (u4) r4 = tail16(in, o4, safe_end);
+        }
+
+        // ---- every lane one step further ----
+        bool eval = false, fin = false;
+        if (want_ir) {
+            irw[0] = r2.x; irw[1] = r2.y; irw[2] = r2.z; irw[3] = r2.w; irw[4] = r3.x; irw[5] = r3.y; irw[6] = r3.z; irw[7] = r3.w;
+            scan = r4;
+        }
+        if (st == F_IR) {
+            look = n - p;
+            if (look < kMinMatch) { first = true; fin = true; } // no INSERT_STRING, no search worth the name (deflate.c:1472: a stale hash_head cannot give three bytes)
+            else { setup_search(irw[0]); if (rank == 0) fin = true; else st = F_GROUP; }
+        } else if (st == F_GROUP) {
+            fresh = false;
+            const uint64_t fl = ((uint64_t)r1.y << 32) | r1.x;
+            uint32_t used = 0;
+            const uint32_t room4 = chain < 4 ? chain : 4;
+            for (uint32_t t = 0; t < 8; t++) { // nearest first: the highest address
+                if (ncand >= room4) break;
+                if (j0 + t + 1 > rank) { lastg = true; break; }
+                used = t + 1;
+                const uint32_t slot = 7 - t;
+                if (!((fl >> (8 * slot)) & 1u)) continue;
+                const uint32_t wd = slot >= 6 ? r0.w : slot >= 4 ? r0.z : slot >= 2 ? r0.y : r0.x, q = (slot & 1) ? wd >> 16 : wd & 0xffffu;
+                const int wq = (int)(q + base) - (int)off;
+                bool stop = wq <= 0;                                                             // NIL, or gone with the slide
+                if (first) { stop = stop || (uint32_t)(w - wq) > kMaxDist; first = first && stop; } // hash_head out of reach: no search (deflate.c:1481)
+                else stop = stop || wq <= limit;                                                 // deflate.c:1163
+                if (stop) { lastg = true; break; }                                               // (the chain ends behind the candidates picked so far)
+                cand[3] = ncand == 3 ? q : cand[3]; cand[2] = ncand == 2 ? q : cand[2]; cand[1] = ncand == 1 ? q : cand[1]; cand[0] = ncand == 0 ? q : cand[0];
+                ncand++;
             }
-            if (!first) match_len = best <= look ? best : look; // a search took place (deflate.c:1166-1167)
-            G[idx] = 1; // INSERT_STRING(strstart)
+            j0 += used;
+            if (ncand) st = F_CAND;
+            else if (lastg || j0 >= rank) fin = true;
+            // else: the next group
+        } else if (st == F_CAND) {
+            cb[0] = r0; cb[1] = r1; cb[2] = r2; cb[3] = r3;
+            eval = true;
+        } else if (st == F_EXT) {
+            const uint32_t d = first_diff16(r0, r1);
+            extl += d;
+            if (d < 16 || extl >= cap) { st = F_CAND; eval = true; }
         }
-        bool cut;
-        if (match_len >= kMinMatch) {
-            tok[ntok++] = tok_match(p - mstart, match_len - kMinMatch);
-            cut = ntok - blk_tok0 == kBlockTokens;
-            if (match_len <= cfg.lazy && look - match_len >= kMinMatch) // max_insert_length (h/deflate.h:176): the strings inside a short match go in
-                for (uint32_t k = 1; k < match_len; k++) G[ir[p + k] & 0xffffu] = 1;
-            p += match_len;
-        } else {
-            tok[ntok++] = tok_lit(in[p]);
-            cut = ntok - blk_tok0 == kBlockTokens;
-            p++;
+        if (eval) { // longest_match's bookkeeping (deflate.c:1126-1163) for the candidates of the round, in order
+            uint32_t l = st == F_CAND && extl ? extl : 0; // (back from F_EXT: the front candidate's length is known)
+            bool known = extl != 0;
+            extl = 0;
+            while (ncand != 0) {
+                if (!known) { l = first_diff16(cb[0], scan); if (l == 16 && cap > 16) { st = F_EXT; extl = 16; break; } }
+                known = false;
+                l = l < cap ? l : cap;
+                bool end = false;
+                if (l > best) { mstart = cand[0]; best = l; end = l >= nice; }
+                end = end || --chain == 0;
+                cand[0] = cand[1]; cand[1] = cand[2]; cand[2] = cand[3]; cb[0] = cb[1]; cb[1] = cb[2]; cb[2] = cb[3]; ncand--; // (registers cannot be indexed: the next one moves to the front)
+                if (end) { fin = true; ncand = 0; }
+            }
+            if (st == F_CAND && !fin) { if (lastg || j0 >= rank) fin = true; else st = F_GROUP; }
         }
-        if (cut) cut_block(p);
+        if (fin) { // the token is decided: emit it, put what deflate_fast inserts into the chains, go to the next one
+            uint32_t L = 1;
+            const uint32_t match_len = first ? kMinMatch - 1 : (best <= look ? best : look); // (no search: nothing in hand, deflate.c:1478-1481)
+            if (look >= kMinMatch) G[idx] = 1; // INSERT_STRING(strstart)
+            if (match_len >= kMinMatch) {
+                tok[ntok++] = tok_match(p - mstart, match_len - kMinMatch);
+                if (match_len <= cfg.lazy && look - match_len >= kMinMatch) { // max_insert_length (h/deflate.h:176): the strings inside a short match go in
+#pragma unroll
+                    for (uint32_t k = 1; k < 7; k++) if (k < match_len) G[irw[k] & 0xffffu] = 1;
+                }
+                L = match_len;
+            } else tok[ntok++] = tok_lit(scan.x & 255u);
+            const bool cut = ntok - blk_tok0 == kBlockTokens;
+            p += L;
+            if (cut) cut_block(p);
+            st = F_IR; extl = 0; ncand = 0;
+            token_top();
+            if (st != F_DONE && L < 8 && n - p >= kMinMatch) { // the next token's idx is at hand: its first round fetches predecessors and ir together
+                uint32_t iv = irw[1];
+#pragma unroll
+                for (uint32_t k = 2; k < 8; k++) iv = L == k ? irw[k] : iv;
+                if ((iv >> 16) != 0) { look = n - p; setup_search(iv); fresh = true; st = F_GROUP; }
+            }
+        }
     }
-    cut_block(p); // the final block (its emission happens in the Huffman stage)
-    meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
+    if (live) { meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n; }
 }
 
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
@@ -1144,7 +1228,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
         static int forced = -1; // chunks per wave (ZGPU_FAST_LANES): a wave's step takes as long as its slowest lane's memory access
         if (forced < 0) { const char *v = getenv("ZGPU_FAST_LANES"); forced = v ? atoi(v) : 0; if (forced < 0 || forced > 64) forced = 0; }
         uint32_t lanes = (uint32_t)forced;
-        if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
+        if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; } // (measured best at 4 GiB: 16 chunks per wave)
         hipLaunchKernelGGL(fast_kernel, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, S, ir, G, tokens, meta, lanes);
         prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
         return;
