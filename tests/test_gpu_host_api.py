@@ -240,3 +240,35 @@ def test_host_buffers_in_batches_with_copies_under_the_kernels():
         else:
             os.environ["ZGPU_BATCH_CHUNKS"] = old
     e.close()
+
+
+def test_zamd_devices_fans_one_call_out_over_engines():
+    """ZAMD_DEVICES names the GPUs one deflate()/compress2() call may use (SURVEY.md 8e through the C boundary: contiguous chunk ranges, one engine
+    and one host thread per device, the ranges' streams laid end to end).  Here both names are device 0 -- two engines side by side on the one
+    GPU of the test box; the stream must be the one-engine stream, byte for byte, zlib and gzip wrapper."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import ctypes as C, hashlib, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import zhost as Z
+from oracle import corpus_py as CP
+data = CP.chunks(0, 7, 1200).tobytes()[: 1200 * 65536 - 12345]   # ~75 MiB: above the 64 MiB from which a call fans out
+rc, z = Z.compress2(data, 6)
+assert rc == 0
+print("ZLIB", hashlib.sha256(z).hexdigest(), len(z))
+zs, codes, info = Z.deflate_stream(data, 4, [(len(data), Z.Z_FINISH)], window_bits=31)
+print("GZIP", hashlib.sha256(zs).hexdigest(), len(zs), info["adler"])
+"""
+    outs = []
+    for devs in (None, "0,0", "0,0,0"):
+        env = dict(os.environ)
+        env.pop("ZAMD_DEVICES", None)
+        if devs:
+            env["ZAMD_DEVICES"] = devs
+        p = subprocess.run([sys.executable, "-c", child % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append([ln for ln in p.stdout.splitlines() if ln.startswith(("ZLIB", "GZIP"))])
+    assert len(outs[0]) == 2 and outs[1] == outs[0] and outs[2] == outs[0], outs

@@ -48,6 +48,54 @@ static zgpu_engine *engine_get(void)
     return e;
 }
 
+/* ---- more than one GPU: ZAMD_DEVICES="0,1,2,3" names the devices one deflate() / compress2() call may use.  Chunks are
+ * independent, so a large input is cut into contiguous chunk ranges, one per device, each compressed by that device's engine from a thread
+ * of its own (no exchange between the devices: the ranges' streams are laid end to end on the host, only the last one carries the final
+ * block; Adler-32 / CRC-32 of the ranges are combined).  The first name is also the device of every other call. ---- */
+#define ZAMD_MAX_DEVICES 16
+static zgpu_engine *g_multi[ZAMD_MAX_DEVICES];
+static pthread_mutex_t g_multi_lock[ZAMD_MAX_DEVICES];
+static int g_multi_n = -1; /* -1: ZAMD_DEVICES not read yet */
+
+static int multi_devices(void) /* engines ready for a fan-out (0: one device only) */
+{
+    pthread_mutex_lock(&g_lock);
+    if (g_multi_n < 0) {
+        g_multi_n = 0;
+        const char *v = getenv("ZAMD_DEVICES");
+        int ids[ZAMD_MAX_DEVICES], n = 0;
+        while (v && *v && n < ZAMD_MAX_DEVICES) {
+            char *end;
+            long d = strtol(v, &end, 10);
+            if (end == v) break;
+            ids[n++] = (int)d;
+            v = *end == ',' ? end + 1 : end;
+        }
+        if (n > 1) {
+            int ok = 1;
+            for (int i = 0; i < n && ok; i++) { ok = zgpu_engine_create(ids[i], &g_multi[i]) == ZGPU_OK; pthread_mutex_init(&g_multi_lock[i], NULL); }
+            if (ok) g_multi_n = n;
+            else for (int i = 0; i < n; i++) if (g_multi[i]) { zgpu_engine_destroy(g_multi[i]); g_multi[i] = NULL; }
+        }
+    }
+    const int n = g_multi_n;
+    pthread_mutex_unlock(&g_lock);
+    return n;
+}
+
+struct multi_job { zgpu_engine *e; pthread_mutex_t *lock; const uint8_t *src; size_t n; zgpu_deflate_params p; uint8_t *dst; uint64_t cap; zgpu_deflate_result r; int rc;
+                   int tuned; uint32_t tune[4]; };
+static void *multi_worker(void *arg)
+{
+    struct multi_job *j = (struct multi_job *)arg;
+    pthread_mutex_lock(j->lock);
+    zgpu_deflate_set_tuning(j->e, j->tuned, j->tune[0], j->tune[1], j->tune[2], j->tune[3]);
+    j->rc = zgpu_deflate_host(j->e, j->src, j->n, &j->p, j->dst, j->cap, NULL, &j->r);
+    zgpu_deflate_set_tuning(j->e, 0, 0, 0, 0, 0);
+    pthread_mutex_unlock(j->lock);
+    return NULL;
+}
+
 /* ---- small utilities ---- */
 EXPORT const char *const z_errmsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
                                          "insufficient memory", "buffer error", "incompatible version", ""}; /* zutil.c:14-24 */
@@ -419,6 +467,42 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     zgpu_engine *e = engine_get();
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     uint64_t cap = zgpu_deflate_bound(n, CHUNK);
+    const int ndev = n >= ((size_t)64 << 20) ? multi_devices() : 0; /* (a fan-out pays from 32 MiB per device on) */
+    if (ndev > 1) {
+        struct multi_job job[ZAMD_MAX_DEVICES];
+        pthread_t th[ZAMD_MAX_DEVICES];
+        const size_t nchunks = (n + CHUNK - 1) / CHUNK;
+        int used = ndev;
+        while (used > 1 && nchunks / (size_t)used < 512) used--;
+        if (!buf_reserve(&s->out, cap + (uint64_t)used * 64)) return Z_MEM_ERROR;
+        uint64_t at = 0;
+        for (int d = 0; d < used; d++) {
+            const size_t c0 = nchunks * (size_t)d / (size_t)used, c1 = nchunks * (size_t)(d + 1) / (size_t)used;
+            const size_t b0 = c0 * CHUNK, b1 = d + 1 == used ? n : c1 * CHUNK;
+            struct multi_job *j = &job[d];
+            j->e = g_multi[d]; j->lock = &g_multi_lock[d]; j->src = src + b0; j->n = b1 - b0;
+            j->p = (zgpu_deflate_params){s->level, CHUNK, ((final && d + 1 == used) ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
+            j->cap = zgpu_deflate_bound(j->n, CHUNK); j->dst = s->out.p + s->out.len + at; at += j->cap;
+            j->tuned = s->tuned; memcpy(j->tune, s->tune, sizeof j->tune); j->rc = ZGPU_ERRNO;
+        }
+        int started = 0;
+        for (; started < used; started++) if (pthread_create(&th[started], NULL, multi_worker, &job[started]) != 0) break;
+        for (int d = 0; d < started; d++) pthread_join(th[d], NULL);
+        for (int d = started; d < used; d++) multi_worker(&job[d]); /* (no thread to be had: the range is compressed here) */
+        uint64_t w = 0;
+        for (int d = 0; d < used; d++) {
+            struct multi_job *j = &job[d];
+            if (j->rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(j->e); return j->rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
+            memmove(s->out.p + s->out.len + w, j->dst, j->r.out_bytes); /* the ranges' streams end to end */
+            w += j->r.out_bytes;
+            s->adler = adler_join(s->adler, j->r.adler32, j->n);
+            if (s->wrap == 2) s->crc = crc_join(s->crc, j->r.crc32, j->n);
+        }
+        s->out.len += w;
+        if (!s->any_block && n > 0) strm->data_type = (int)job[0].r.data_type;
+        s->any_block = 1;
+        return Z_OK;
+    }
     if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
     zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
     zgpu_deflate_result r;
