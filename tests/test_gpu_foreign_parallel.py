@@ -137,3 +137,41 @@ def test_zlib_api_uncompress_of_a_foreign_stream(eng):
     rc, out = Z.uncompress(z, len(data))
     assert rc == 0 and out == data
     assert eng.spec_counts()[0] == before[0] + 1
+
+
+def test_preset_dictionary_in_front_of_the_first_piece(eng):
+    """inflateSetDictionary (qcsrc/inflate.c:1200-1236) with a stream decoded in pieces: the first piece may reach back into the dictionary, the others
+    into what the pieces in front of them produced; a stream that needs a dictionary it does not get is an error of the stream."""
+    import zlib_amd
+    text = corpus(eng, 1, 900, 200)
+    zdict = text[5000:5000 + 32768]
+    data = zdict[1000:9000] * 3 + text[1 << 20: 9 << 20]  # starts with bytes that are cheapest as copies from the dictionary
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, zdict)
+    raw = co.compress(data) + co.flush()
+    eng.inflate_set_dictionary(zdict)
+    try:
+        before = eng.spec_counts()
+        out = eng.inflate_stream_host(raw, len(data))
+        assert out == data
+        assert eng.spec_counts()[0] == before[0] + 1
+    finally:
+        eng.inflate_set_dictionary(b"")
+    with pytest.raises(zlib_amd.EngineError) as ei:
+        eng.inflate_stream_host(raw, len(data))
+    assert ei.value.code == -3
+
+
+def test_a_stream_longer_than_the_one_workgroup_decoder_takes(eng):
+    """640 MiB of compressed input (the one-workgroup decoder stops at 512 MiB: its bit counts are 32 bits wide): stored blocks of random bytes with
+    compressible stretches between them, level 1.  Only the pieces can decode it; bytes and CRC-32 must be the input's."""
+    rnd = np.random.default_rng(11).integers(0, 256, 160 << 20, dtype=np.uint8).tobytes()
+    text = corpus(eng, 1, 123, 256)
+    data = b"".join(rnd[i * (40 << 20):(i + 1) * (40 << 20)] + text for i in range(4)) * 4   # 4 x (160 MiB random + 64 MiB text) = 896 MiB
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    raw = b"".join(co.compress(data[i:i + (64 << 20)]) for i in range(0, len(data), 64 << 20)) + co.flush()
+    assert len(raw) > (1 << 29) + (64 << 20)
+    dst = np.zeros(len(data), dtype=np.uint8)
+    before = eng.spec_counts()
+    out = eng.inflate_stream_host(raw, len(data), out=dst)
+    assert eng.spec_counts() == (before[0] + 1, before[1])
+    assert eng.last_inflate.crc32 == zlib.crc32(data) and out.tobytes() == data
