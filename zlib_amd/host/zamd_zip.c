@@ -66,6 +66,7 @@ EXPORT int zamd_zip_add(zamd_zip *z, const char *name, const void *data, unsigne
     if (!z || !z->fp || (!data && len) || level < -1 || level > 9 || len >= 0xFFFFFFFFul) return ZAMD_ZIP_PARAMERROR;
     if (!name) name = "-";
     const size_t nname = strlen(name), ncomm = comment ? strlen(comment) : 0;
+    if (nname > 0xFFFFu || ncomm > 0xFFFFu || z->entries >= 0xFFFFu) return ZAMD_ZIP_PARAMERROR; /* 16-bit fields (no zip64, as minizip 1.01e) */
     const int method = level != 0 ? Z_DEFLATED : 0;
     unsigned long flag = 0;
     if (level == 8 || level == 9) flag |= 2;
@@ -125,7 +126,7 @@ EXPORT int zamd_zip_close(zamd_zip *z, const char *global_comment)
 }
 
 /* ------------------------------------------------------------------ reading */
-struct zamd_unzip { FILE *fp; zamd_zip_entry *ent; int n; };
+struct zamd_unzip { FILE *fp; zamd_zip_entry *ent; int n; long fsize; };
 
 EXPORT zamd_unzip *zamd_unzip_open(const char *path)
 {
@@ -165,6 +166,7 @@ EXPORT zamd_unzip *zamd_unzip_open(const char *path)
             o += 46 + nn + nx + nc;
         }
         u->n = (int)n;
+        u->fsize = fsize;
     }
     free(tail); free(cd);
     u->fp = fp;
@@ -194,6 +196,8 @@ EXPORT long zamd_unzip_read(zamd_unzip *u, int i, void *out, unsigned long cap)
     const zamd_zip_entry *t = &u->ent[i];
     if (t->uncompressed_size > cap) return ZAMD_ZIP_PARAMERROR;
     if (t->method != 0 && t->method != Z_DEFLATED) return ZAMD_ZIP_BADZIPFILE;
+    /* (a directory that claims more than the file holds is damaged: nothing is allocated on its word) */
+    if ((unsigned long)u->fsize < 30ul || t->local_header_offset > (unsigned long)u->fsize - 30ul || t->compressed_size > (unsigned long)u->fsize - t->local_header_offset - 30ul) return ZAMD_ZIP_BADZIPFILE;
     uint8_t lh[30];
     if (fseek(u->fp, (long)t->local_header_offset, SEEK_SET) || fread(lh, 1, 30, u->fp) != 30) return ZAMD_ZIP_ERRNO;
     if (get32(lh) != 0x04034b50ul || (int)get16(lh + 8) != t->method) return ZAMD_ZIP_BADZIPFILE; /* unzip.c:983-1050 */
