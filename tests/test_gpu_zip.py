@@ -156,6 +156,14 @@ def test_foreign_archive_and_crc_damage(L, tmp_path):
     bad.write_bytes(bytes(raw))
     got = read_zip(L, bad)
     assert got[0][1] == -105 and got[1][1] == -105 and got[2][1] == 0 and got[3][2] == members[3][1]
+    # a directory that claims more compressed bytes than the file holds: refused before anything is read or allocated
+    raw = bytearray(p.read_bytes())
+    cd = raw.find(b"PK\x01\x02")
+    raw[cd + 20:cd + 24] = (0xFFFFFF00).to_bytes(4, "little")
+    liar = tmp_path / "liar.zip"
+    liar.write_bytes(bytes(raw))
+    got = read_zip(L, liar)
+    assert got[0][1] == -103 and got[3][2] == members[3][1]
     # not an archive
     junk = tmp_path / "junk.zip"
     junk.write_bytes(b"PK" + bytes(100))
