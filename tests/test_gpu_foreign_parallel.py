@@ -175,3 +175,43 @@ def test_a_stream_longer_than_the_one_workgroup_decoder_takes(eng):
     out = eng.inflate_stream_host(raw, len(data), out=dst)
     assert eng.spec_counts() == (before[0] + 1, before[1])
     assert eng.last_inflate.crc32 == zlib.crc32(data) and out.tobytes() == data
+
+
+def test_many_streams_around_the_threshold_of_the_pieces(eng):
+    """Forty streams of the system zlib between 64 KiB and 6 MiB of compressed size -- levels, strategies, window sizes, sync and full flushes at random
+    places, inputs from text to noise, some with bytes behind the end: whichever way a stream goes (too short for pieces, too few block starts,
+    pieces, repair, one workgroup), the bytes are the input's and the end of the stream is where the system zlib says it is."""
+    rng = np.random.default_rng(2024)
+    text = corpus(eng, 1, 31, 128)
+    mix = corpus(eng, 0, 32, 128)
+    noise = rng.integers(0, 256, 8 << 20, dtype=np.uint8).tobytes()
+    for k in range(40):
+        kind = int(rng.integers(0, 4))
+        n = int(rng.integers(150_000, 8_000_000))
+        src = (text, mix, noise, text)[kind]
+        o = int(rng.integers(0, len(src) - n))
+        data = src[o:o + n]
+        if kind == 3:  # stretches of noise inside text
+            cut = n // 3
+            data = data[:cut] + noise[o % 1000: o % 1000 + cut] + data[cut:]
+        level = int(rng.choice([1, 3, 6, 9]))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED]))
+        wbits = -int(rng.choice([15, 15, 15, 12, 9]))
+        co = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+        parts, pos = [], 0
+        while pos < len(data):
+            step = int(rng.integers(50_000, 2_000_000))
+            parts.append(co.compress(data[pos:pos + step]))
+            pos += step
+            r = rng.random()
+            if pos < len(data) and r < 0.15:
+                parts.append(co.flush(zlib.Z_SYNC_FLUSH))
+            elif pos < len(data) and r < 0.2:
+                parts.append(co.flush(zlib.Z_FULL_FLUSH))
+        parts.append(co.flush())
+        raw = b"".join(parts)
+        tail = b"" if k % 3 else bytes(rng.integers(0, 256, int(rng.integers(1, 5000)), dtype=np.uint8))
+        out = eng.inflate_stream_host(raw + tail, len(data) + 100, flags=1)
+        assert out == data, (k, level, strategy, wbits, len(raw))
+        assert eng.last_inflate.stream_end == 1 and eng.last_inflate.in_used == len(raw), (k, eng.last_inflate.in_used, len(raw))
+        assert eng.last_inflate.crc32 == zlib.crc32(data), k
