@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--gib", type=float, default=4.0, help="GiB of input per GPU")
     ap.add_argument("--workload", default="silesia-mix", choices=["silesia-mix", "log-text"])
-    ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel", "sorted", "walk"])
+    ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel", "sorted", "walk", "fast"])
     ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,7 +141,7 @@ def main():
     cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
     dst = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
-    lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL, "sorted": gpu.LZ_SORTED, "walk": gpu.LZ_WALK}[a.lz]
+    lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL, "sorted": gpu.LZ_SORTED, "walk": gpu.LZ_WALK, "fast": gpu.LZ_FAST}[a.lz]
     stream = torch.cuda.current_stream().cuda_stream
     gather_buf = None
     state = {}
