@@ -274,7 +274,10 @@ __device__ inline uint32_t decode_sym(BitSrc &b, const uint32_t *tab, uint32_t t
 
 // The header of a dynamic block behind its three type bits (inflate.c:811-880): the counts, the code-length code, the code lengths, the
 // two decoding tables.  Returns 0 or the message of the first rule broken.  Wave-uniform; shared by the reader and the block finder.
-template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b, uint32_t lane, CodeRows &lrows, CodeRows &drows)
+// QUICK (the block finder, which only wants yes or no): the lengths' sums are kept while they are read, and a literal/length or distance code that is
+// over-subscribed already ends the parse -- a header that is none usually is within a few dozen lengths, not after three hundred.  (The decoder proper
+// reads them all first: an invalid repeat further on is the error zlib reports, inflate.c:838-866 before :870-885.)
+template <bool QUICK, class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b, uint32_t lane, CodeRows &lrows, CodeRows &drows)
 {
     refill(b, L.stage);
     const uint32_t nlen = peek(b, 5) + 257; drop(b, 5);
@@ -320,7 +323,7 @@ template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b
     }
     wave_sync();
     for (uint32_t s = lane; s < 320; s += 64) L.lens[s] = 0;
-    uint32_t have = 0, prev = 0;
+    uint32_t have = 0, prev = 0, qkl = 0, qkd = 0;
     while (have < nlen + ndist) {
         stage_fill(b, L.stage, lane);
         refill(b, L.stage);
@@ -329,13 +332,22 @@ template <class LDS> __device__ inline uint32_t dynamic_header(LDS &L, BitSrc &b
         if (!ce) return kMsgCodeLens;
         drop(b, ce & 255u);
         const uint32_t s = ce >> 8;
-        if (s < 16) { if (lane == 0) L.lens[have] = (uint16_t)s; prev = s; have++; continue; }
+        if (s < 16) {
+            if (lane == 0) L.lens[have] = (uint16_t)s;
+            if (QUICK && s) { if (have < nlen) qkl += 32768u >> s; else qkd += 32768u >> s; if (qkl > 32768u || qkd > 32768u) return kMsgLitLens; }
+            prev = s; have++; continue;
+        }
         uint32_t rep, val = 0;
         refill(b, L.stage);
         if (s == 16) { if (have == 0) return kMsgRepeat; val = prev; rep = 3 + peek(b, 2); drop(b, 2); }
         else if (s == 17) { rep = 3 + peek(b, 3); drop(b, 3); }
         else { rep = 11 + peek(b, 7); drop(b, 7); }
         if (have + rep > nlen + ndist) return kMsgRepeat;
+        if (QUICK && val) { // (a run of equal lengths may straddle the two codes)
+            const uint32_t inl = have >= nlen ? 0u : (have + rep <= nlen ? rep : nlen - have);
+            qkl += inl * (32768u >> val); qkd += (rep - inl) * (32768u >> val);
+            if (qkl > 32768u || qkd > 32768u) return kMsgLitLens;
+        }
         if (lane < rep) L.lens[have + lane] = (uint16_t)val;
         if (lane + 64 < rep) L.lens[have + lane + 64] = (uint16_t)val;
         if (lane + 128 < rep) L.lens[have + lane + 128] = (uint16_t)val;
@@ -554,7 +566,7 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
                 build_table(L, L.lens, 32, 2, kDBits, L.dtab, L.dsym, L.dcount, lane);
                 drows = load_rows(L, L.dcount, lane);
             } else {
-                err = dynamic_header(L, b, lane, lrows, drows);
+                err = dynamic_header<false>(L, b, lane, lrows, drows);
                 if (err) break;
             }
             wave_sync();
@@ -1079,6 +1091,18 @@ namespace zgpu {
 //   4. spec_window_kernel: piece by piece, the last 32 KiB of output with the markers replaced (the only serial step: 32 K look-ups each);
 //      spec_resolve_kernel: every page of symbols to its place in the output, markers looked up in the window of the piece in front.
 // ======================================================================================================================================
+#ifdef ZGPU_FIND_TIME // debug build only: clock per phase of the block finder, summed over the finders
+__device__ unsigned long long find_time[8];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_find_time(unsigned long long *out, int reset)
+{
+    unsigned long long z[8] = {};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(find_time), sizeof z);
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(find_time), z, sizeof z);
+}
+#define FT(i) do { const unsigned long long t_ = wall_clock64(); ft[i] += t_ - ftp; ftp = t_; } while (0)
+#else
+#define FT(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes, uint64_t spacing, uint32_t ntargets, uint64_t *found)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1090,6 +1114,9 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
     const uint32_t *g32 = reinterpret_cast<const uint32_t *>(in); // (the input buffer is a device allocation: aligned)
     const uint64_t gdwords = (in_bytes + 3) >> 2;
     uint64_t result = ~0ull;
+#ifdef ZGPU_FIND_TIME
+    unsigned long long ft[8] = {}, ftp = wall_clock64(), nval = 0;
+#endif
     // does a dynamic block the decoder would accept start at bit `cand` (its three type bits are not looked at)?
     auto dynamic_at = [&](uint64_t cand) -> bool {
         BitSrc b;
@@ -1104,7 +1131,7 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
         drop(b, (uint32_t)cand & 31u);
         drop(b, 3);
         CodeRows lr{}, dr{};
-        const uint32_t err = dynamic_header(L, b, lane, lr, dr);
+        const uint32_t err = dynamic_header<true>(L, b, lane, lr, dr);
         wave_sync();
         // (a block needs its end-of-block code; inflate_table does not ask for it, a block start worth trusting does)
         return !err && uni(L.lens[256]) != 0 && consumed_bits(b) <= b.seg_bits;
@@ -1145,6 +1172,7 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
             }
         }
     }
+    FT(0); // the stored sieve
     // the bytes to scan come through LDS, kScanBytes at a time
     uint32_t *scan = reinterpret_cast<uint32_t *>(L.out);
     const uint4 *g128 = reinterpret_cast<const uint4 *>(in);
@@ -1161,6 +1189,7 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
         }
         wave_sync();
         const uint64_t blk_hi = blk + kScanBytes * 8 < hi_bit ? blk + kScanBytes * 8 : hi_bit;
+        FT(1); // staging
         // Three sieves.  (1) every lane, its own bit offset: BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29 -- one offset in nine passes; the survivors
         // are listed in LDS in offset order.  (2) whenever 64 are listed (and at the end of the block), one per lane: the code-length code must be
         // complete (inftrees.c:106-138: sum of 2^-len == 1).  (3) what is left, in order, through the decoder's own header parse.
@@ -1176,6 +1205,7 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                 listed += (uint32_t)__builtin_popcountll(pm);
                 if (listed < 64 && base + 64 < blk_hi) continue;
             }
+            FT(2); // sieve 1
             wave_sync();
             while (listed && result == ~0ull && (listed >= 64 || base + 64 >= blk_hi)) {
                 const uint32_t take = listed < 64 ? listed : 64;
@@ -1201,15 +1231,23 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                 if (lane + take < listed) list[lane] = (uint16_t)moved;
                 listed -= take;
                 wave_sync();
+                FT(3); // sieve 2
                 while (m) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
                     const uint64_t cand = blk + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
+#ifdef ZGPU_FIND_TIME
+                    nval++;
+#endif
                     if (dynamic_at(cand)) { result = cand; break; }
                 }
+                FT(4); // header parses
             }
         }
     }
     if (lane == 0) { found[t - 1] = result; found[ntargets + t - 1] = stored; }
+#ifdef ZGPU_FIND_TIME
+    if (lane == 0) { ft[5] = nval; ft[6] = 1; for (int i = 0; i < 8; i++) if (ft[i]) atomicAdd(&find_time[i], ft[i]); }
+#endif
 }
 
 // The windows: window[i] = the last 32 KiB of the output up to the end of piece i = piece i's tail with its markers looked up in window[i - 1] -- a
