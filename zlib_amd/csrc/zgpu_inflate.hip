@@ -72,8 +72,9 @@ template <typename RingT, uint32_t kRing = kOutRing> struct InflateLdsT {
 using InflateLds = InflateLdsT<uint8_t>;
 using InflateLdsSpec = InflateLdsT<uint16_t>;
 constexpr uint32_t kScanBytes = 4096; // the block finder reads the input through LDS in pieces of this size (+ the 16 bytes a bit offset at the end reaches into)
-using InflateLdsFind = InflateLdsT<uint8_t, kScanBytes + 64>;
-static_assert(sizeof(InflateLdsFind) <= 12288, "thirteen finder waves per CU");
+constexpr uint32_t kFindList = 1024; // candidates listed between two rounds of the second sieve (a group of 2048 offsets yields 683 at most: one in three)
+using InflateLdsFind = InflateLdsT<uint8_t, kScanBytes + 64 + kFindList * 2>;
+static_assert(sizeof(InflateLdsFind) <= 14336, "eleven finder waves per CU");
 static_assert(sizeof(InflateLds) <= 40448, "four waves per CU");
 static_assert(sizeof(InflateLdsSpec) <= 81920, "two workgroups per CU");
 
@@ -1190,26 +1191,31 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
         wave_sync();
         const uint64_t blk_hi = blk + kScanBytes * 8 < hi_bit ? blk + kScanBytes * 8 : hi_bit;
         FT(1); // staging
-        // Three sieves.  (1) every lane, its own bit offset: BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29 -- one offset in nine passes; the survivors
-        // are listed in LDS in offset order.  (2) whenever 64 are listed (and at the end of the block), one per lane: the code-length code must be
-        // complete (inftrees.c:106-138: sum of 2^-len == 1).  (3) what is left, in order, through the decoder's own header parse.
+        // Three sieves.  (1) BFINAL 0, BTYPE 2, HLIT <= 29, HDIST <= 29 -- one offset in nine passes -- for 32 offsets per lane at a time, on the 64 bits
+        // that start at the lane's first offset: the type bits are ~x & ~(x >> 1) & (x >> 2), a count of 30 or 31 has its upper four bits set; the
+        // survivors are listed in LDS in offset order.  (2) whenever 64 are listed (and at the end of the block), one per lane: the code-length
+        // code must be complete (inftrees.c:106-138: sum of 2^-len == 1).  (3) what is left, in order, through the decoder's own header parse.
         uint32_t listed = 0;
-        uint16_t *list = reinterpret_cast<uint16_t *>(L.tok); // 128 entries are used at most (63 left over + 64 new)
-        for (uint64_t base = blk; base < blk_hi + 64 && result == ~0ull; base += 64) {
+        uint16_t *list = reinterpret_cast<uint16_t *>(L.out + kScanBytes + 64);
+        for (uint64_t base = blk; base < blk_hi + 2048 && result == ~0ull; base += 2048) {
             if (base < blk_hi) {
-                const uint32_t rel = (uint32_t)(base - blk) + lane, wi = rel >> 5, sh = rel & 31u;
-                const uint32_t b0 = __builtin_amdgcn_alignbit(scan[wi + 1], scan[wi], sh);
-                const bool pre = base + lane < blk_hi && (b0 & 7u) == 4u && ((b0 >> 3) & 31u) <= 29 && ((b0 >> 8) & 31u) <= 29;
-                const uint64_t pm = __ballot(pre);
-                if (pre) list[listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))] = (uint16_t)rel;
-                listed += (uint32_t)__builtin_popcountll(pm);
-                if (listed < 64 && base + 64 < blk_hi) continue;
+                const uint32_t rel0 = (uint32_t)(base - blk) + lane * 32, wi = rel0 >> 5;
+                const uint64_t x = ((uint64_t)scan[wi + 1] << 32) | scan[wi];
+                uint64_t cm = ~x & ~(x >> 1) & (x >> 2) & ~((x >> 4) & (x >> 5) & (x >> 6) & (x >> 7)) & ~((x >> 9) & (x >> 10) & (x >> 11) & (x >> 12)) & 0xFFFFFFFFull;
+                const uint64_t left = base + lane * 32 < blk_hi ? blk_hi - (base + lane * 32) : 0; // offsets of this lane inside the block
+                if (left < 32) cm &= (1ull << left) - 1;
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(cm), incl = wave_prefix_sum(cnt);
+                uint32_t at = listed + incl - cnt;
+                while (cm) { list[at++] = (uint16_t)(rel0 + (uint32_t)__builtin_ctzll(cm)); cm &= cm - 1; }
+                listed += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (listed < 64 && base + 2048 < blk_hi) continue;
             }
             FT(2); // sieve 1
             wave_sync();
-            while (listed && result == ~0ull && (listed >= 64 || base + 64 >= blk_hi)) {
+            uint32_t lhead = 0; // the list is taken from the front, 64 at a time; what is left (fewer than 64) moves down behind the loop
+            while (listed && result == ~0ull && (listed >= 64 || base + 2048 >= blk_hi)) {
                 const uint32_t take = listed < 64 ? listed : 64;
-                const uint32_t rel = lane < take ? list[lane] : 0u, wi = rel >> 5, sh = rel & 31u;
+                const uint32_t rel = lane < take ? list[lhead + lane] : 0u, wi = rel >> 5, sh = rel & 31u;
                 uint32_t w[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) w[k] = scan[wi + k];
@@ -1225,12 +1231,7 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                 for (uint32_t i = 0; i < 9; i++) kraft += (128u >> ((ymid >> (3 * i)) & 7u)) & 127u;
                 const bool ok = lane < take && blk + rel + 17 + 3 * ncode < hi_bit && kraft == 128;
                 uint64_t m = __ballot(ok);
-                // the rest of the list moves to the front (before the header parse: it uses L.tok's neighbours, not L.tok)
-                const uint32_t moved = lane + take < listed ? list[lane + take] : 0u;
-                wave_sync();
-                if (lane + take < listed) list[lane] = (uint16_t)moved;
-                listed -= take;
-                wave_sync();
+                lhead += take; listed -= take;
                 FT(3); // sieve 2
                 while (m) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
@@ -1241,6 +1242,12 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                     if (dynamic_at(cand)) { result = cand; break; }
                 }
                 FT(4); // header parses
+            }
+            if (lhead) { // fewer than 64 are left: to the front
+                const uint32_t moved = lane < listed ? list[lhead + lane] : 0u;
+                wave_sync();
+                if (lane < listed) list[lane] = (uint16_t)moved;
+                wave_sync();
             }
         }
     }
