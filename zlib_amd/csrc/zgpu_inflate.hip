@@ -1092,6 +1092,70 @@ namespace zgpu {
 //   4. spec_window_kernel: piece by piece, the last 32 KiB of output with the markers replaced (the only serial step: 32 K look-ups each);
 //      spec_resolve_kernel: every page of symbols to its place in the output, markers looked up in the window of the piece in front.
 // ======================================================================================================================================
+// The block finder's third sieve, one candidate per lane: do the code lengths behind the header at bit `cb` (its three type bits included) describe
+// a literal/length and a distance code inflate_table would accept (inftrees.c:106-138), with a code for the end of the block?  Everything a lane
+// needs is its own: the bits come from global memory, the code-length code is decoded canonically (counts per length, symbols in
+// (length, symbol) order in 19 bytes of LDS), the lengths are summed as they are read.  A yes is confirmed by the decoder's own parse.
+__device__ inline bool lane_header_ok(const uint32_t *__restrict__ g32, uint64_t gdwords, uint64_t cb, uint64_t total_bits, uint8_t *sorted)
+{
+    auto bits33 = [&](uint64_t p) -> uint64_t { // the 33 bits (at least) at absolute bit p
+        const uint64_t wi = p >> 5;
+        const uint32_t w0 = wi < gdwords ? g32[wi] : 0u, w1 = wi + 1 < gdwords ? g32[wi + 1] : 0u;
+        return ((((uint64_t)w1) << 32) | w0) >> (p & 31u);
+    };
+    uint64_t p = cb + 3;
+    if (p + 14 + 57 > total_bits) return false;
+    const uint32_t hdr = (uint32_t)bits33(p) & 0x3fffu; p += 14;
+    const uint32_t nlen = (hdr & 31u) + 257, ndist = ((hdr >> 5) & 31u) + 1, ncode = (hdr >> 10) + 4;
+    if (nlen > 286 || ndist > 30) return false;
+    const uint64_t y = (bits33(p) & 0x3fffffffull) | ((bits33(p + 30) & 0x7ffffffull) << 30);
+    p += 3 * ncode;
+    // lengths by symbol (three bits each), counts by length (a byte each)
+    constexpr uint32_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint64_t bysym = 0, counts = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 19; i++) {
+        const uint32_t l = i < ncode ? (uint32_t)(y >> (3 * i)) & 7u : 0u;
+        bysym |= (uint64_t)l << (3 * order[i]);
+        counts += l ? 1ull << (8 * l) : 0ull;
+    }
+    uint32_t k = 0;
+    for (uint32_t l = 1; l <= 7; l++)
+        for (uint32_t sy = 0; sy < 19; sy++) if (((uint32_t)(bysym >> (3 * sy)) & 7u) == l) sorted[k++] = (uint8_t)sy;
+    const uint32_t all = nlen + ndist;
+    uint32_t have = 0, prev = 0, kl = 0, kd = 0, eob = 0, big = 0; // big: bit 0 a literal/length code longer than one bit, bit 1 a distance code
+    while (have < all) {
+        if (p + 14 > total_bits) return false;
+        uint32_t w = (uint32_t)bits33(p);
+        uint32_t code = 0, first = 0, index = 0, sym = 0xffu, len = 1;
+        for (; len <= 7; len++) {
+            code |= w & 1u; w >>= 1;
+            const uint32_t cnt = (uint32_t)(counts >> (8 * len)) & 255u;
+            if (code < first + cnt) { sym = sorted[index + code - first]; break; }
+            index += cnt; first = (first + cnt) << 1; code <<= 1;
+        }
+        if (sym == 0xffu) return false;
+        p += len;
+        uint32_t rep = 1, val = sym;
+        if (sym >= 16) {
+            if (sym == 16) { if (have == 0) return false; val = prev; rep = 3 + (w & 3u); p += 2; }
+            else if (sym == 17) { val = 0; rep = 3 + (w & 7u); p += 3; }
+            else { val = 0; rep = 11 + (w & 127u); p += 7; }
+            if (have + rep > all) return false;
+        }
+        if (val) {
+            const uint32_t inl = have >= nlen ? 0u : (have + rep <= nlen ? rep : nlen - have), unit = 32768u >> val;
+            kl += inl * unit; kd += (rep - inl) * unit;
+            if (kl > 32768u || kd > 32768u) return false;
+            if (val > 1) big |= (inl ? 1u : 0u) | (rep > inl ? 2u : 0u);
+            if (have <= 256 && have + rep > 256) eob = val;
+        }
+        prev = val; have += rep;
+    }
+    const bool lit_ok = kl == 32768u || (kl == 16384u && !(big & 1u));
+    const bool dist_ok = kd == 32768u || kd == 0u || (kd == 16384u && !(big & 2u));
+    return eob != 0 && lit_ok && dist_ok;
+}
 #ifdef ZGPU_FIND_TIME // debug build only: clock per phase of the block finder, summed over the finders
 __device__ unsigned long long find_time[8];
 extern "C" __attribute__((visibility("default"))) void zgpu_debug_find_time(unsigned long long *out, int reset)
@@ -1141,6 +1205,24 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
     // stream's.  The first byte offset B of the region that reads as LEN, ~LEN behind three zero header bits and zero padding, and whose block is
     // followed by a header that holds as well (stored: LEN, ~LEN again; dynamic: as above) is reported too: the host starts a piece AT its LEN and
     // strikes the dynamic "starts" found inside the block's bytes.
+    // the candidates that passed the second sieve wait here (a handful per block) until a lane each can read their code lengths
+    uint64_t *wait = reinterpret_cast<uint64_t *>(L.tok); // 64 entries
+    uint32_t nwait = 0;
+    auto settle = [&]() { // third sieve for up to 64 waiting candidates at once, then the decoder's parse for what is left, in order
+        const uint64_t cb = lane < nwait ? wait[lane] : 0ull;
+        const bool yes = lane < nwait && lane_header_ok(g32, gdwords, cb, total_bits, reinterpret_cast<uint8_t *>(L.ltab) + lane * 20);
+        uint64_t mm = __ballot(yes);
+        nwait = 0;
+        wave_sync();
+        while (mm && result == ~0ull) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
+            const uint64_t cand = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cb >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cb, (int)l);
+#ifdef ZGPU_FIND_TIME
+            nval++;
+#endif
+            if (dynamic_at(cand)) result = cand;
+        }
+    };
     uint64_t stored = ~0ull;
     {
         const uint64_t lo_byte = (uint64_t)t * spacing, hi_byte = hi_bit >> 3;
@@ -1233,16 +1315,15 @@ __global__ void __launch_bounds__(64) spec_find_kernel(const uint8_t *__restrict
                 uint64_t m = __ballot(ok);
                 lhead += take; listed -= take;
                 FT(3); // sieve 2
-                while (m) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(m); m &= m - 1;
-                    const uint64_t cand = blk + (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)l);
-#ifdef ZGPU_FIND_TIME
-                    nval++;
-#endif
-                    if (dynamic_at(cand)) { result = cand; break; }
+                if (m) {
+                    const uint32_t add = (uint32_t)__builtin_popcountll(m);
+                    if (nwait + add > 64) { settle(); FT(4); }
+                    if (ok) wait[nwait + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = blk + rel;
+                    nwait += add;
+                    wave_sync();
                 }
-                FT(4); // header parses
             }
+            if (nwait >= 32 || (nwait && base + 2048 >= blk_hi && blk + kScanBytes * 8 >= hi_bit)) { settle(); FT(4); } // (half a wave of them, or the region's last)
             if (lhead) { // fewer than 64 are left: to the front
                 const uint32_t moved = lane < listed ? list[lhead + lane] : 0u;
                 wave_sync();
