@@ -1711,6 +1711,19 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
     // failing segment into its successor, then -- and at once when a segment fails in the way a kept window looks (a distance that
     // reaches back before the segment, more than 64 KiB of output) -- the stream is decoded from end to end by one workgroup.
     bool whole = false;
+    // not one marker in a long body: no chunked stream of this library looks like that -- the pieces are tried at once (the pass below would decode 64 KiB
+    // of it, find that the one segment goes on, and come to the same place)
+    bool tried_pieces = false;
+    if (ncand == 0 && in_bytes >= (1u << 20)) {
+        tried_pieces = true;
+        const int src = inflate_spec_run(e, d_in, static_cast<const uint8_t *>(in), in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode);
+        if (src != 1) {
+            if (src != ZGPU_OK) return src;
+            if (out && res->out_bytes) ZGPU_HIP_CHECK(hipMemcpy(out, engine_stage_out(e), res->out_bytes, hipMemcpyDeviceToHost));
+            if (offsets_out) *offsets_out = b;
+            return ZGPU_OK;
+        }
+    }
     // stream mode: input that ends with a flush marker may simply be all there is so far -- then the last segment is a segment like the
     // others and none of them has to hold the final block
     const uint8_t *hin = static_cast<const uint8_t *>(in);
@@ -1729,7 +1742,7 @@ static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes
         whole = true;
         break;
     }
-    if (whole) {
+    if (whole && !tried_pieces) {
         const int src = inflate_spec_run(e, d_in, hin, in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode);
         if (src != 1 && src != ZGPU_OK) return src;
         whole = src == 1;
