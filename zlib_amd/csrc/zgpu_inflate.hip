@@ -204,31 +204,64 @@ __device__ inline uint32_t make_entry(uint32_t kind, uint32_t s, uint32_t l)
 template <class LDS> __device__ __noinline__ uint32_t build_table(LDS &L, const uint16_t *lens, uint32_t n, uint32_t kind, uint32_t tbits, uint32_t *tab,
                                              uint16_t *sorted, uint16_t *count, uint32_t lane)
 {
+    // All lanes together (round 2; one lane walking 286 lengths twice was four fifths of a dynamic block's header): a lane holds the lengths of
+    // symbols lane, 64 + lane, ...; counts per length and a symbol's place among those of its length are ballots.
     wave_sync();
     for (uint32_t i = lane; i < (1u << tbits); i += 64) tab[i] = 0;
-    if (lane == 0) {
-        uint16_t *cnt = count, *offs = L.work_offs, *first = L.work_first, *start = L.work_start;
-        for (int l = 0; l < 16; l++) cnt[l] = 0;
-        for (uint32_t s2 = 0; s2 < n; s2++) cnt[lens[s2]]++;
-        int maxl = 15; while (maxl >= 1 && cnt[maxl] == 0) maxl--;
-        uint32_t rc = 0;
-        if (maxl > 0) {
-            int left = 1;
-            for (int l = 1; l <= 15; l++) { left <<= 1; left -= (int)cnt[l]; if (left < 0) { rc = 1; break; } }
-            if (!rc && left > 0 && (kind == 0 || maxl != 1)) rc = 1; // incomplete set
+    constexpr uint32_t kGroups = 5; // 320 lengths at most
+    const uint32_t ng = (n + 63) >> 6;
+    uint32_t ml[kGroups];
+#pragma unroll
+    for (uint32_t g = 0; g < kGroups; g++) { const uint32_t s2 = g * 64 + lane; ml[g] = s2 < n ? lens[s2] : 0u; }
+    uint32_t cnt[16];
+    cnt[0] = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15; l++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kGroups; g++) if (g < ng) c += (uint32_t)__builtin_popcountll(__ballot(ml[g] == l));
+        cnt[l] = c;
+    }
+    uint32_t maxl = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15; l++) maxl = cnt[l] ? l : maxl;
+    uint32_t rc = 0;
+    if (maxl > 0) { // inflate_table's rules, inftrees.c:106-138
+        int left = 1;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) { left <<= 1; left -= (int)cnt[l]; if (left < 0) rc = 1; }
+        if (!rc && left > 0 && (kind == 0 || maxl != 1)) rc = 1; // incomplete set
+    }
+    uint32_t first[16], start[16], c = 0, o = 0;
+    first[0] = 0; start[0] = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; first[l] = c; start[l] = o; o += cnt[l]; }
+    // the per-length rows where the long-code walk and the fill below look for them
+    {
+        uint32_t mc = 0, mf = 0, ms = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) { mc = lane == l ? cnt[l] : mc; mf = lane == l ? first[l] : mf; ms = lane == l ? start[l] : ms; }
+        if (lane < 16) { count[lane] = (uint16_t)mc; L.work_first[lane] = (uint16_t)mf; L.work_start[lane] = (uint16_t)ms; }
+        if (lane == 0) { L.build_n = o; L.build_rc = rc; }
+    }
+    if (rc == 0) {
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            if (cnt[l] == 0) continue;
+            uint32_t base = start[l];
+#pragma unroll
+            for (uint32_t g = 0; g < kGroups; g++) {
+                if (g >= ng) continue;
+                const uint64_t m = __ballot(ml[g] == l);
+                if (ml[g] == l) sorted[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(g * 64 + lane);
+                base += (uint32_t)__builtin_popcountll(m);
+            }
         }
-        uint32_t c = 0; offs[1] = 0; cnt[0] = 0;
-        for (int l = 1; l <= 15; l++) { c = (c + cnt[l - 1]) << 1; first[l] = (uint16_t)c; if (l < 15) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]); }
-        for (int l = 1; l <= 15; l++) start[l] = offs[l];
-        L.build_n = (uint32_t)offs[15] + cnt[15];
-        if (!rc) for (uint32_t s2 = 0; s2 < n; s2++) { const uint32_t l = lens[s2]; if (l) sorted[offs[l]++] = (uint16_t)s2; }
-        L.build_rc = rc;
     }
     wave_sync();
-    const uint32_t rc = L.build_rc;
     if (rc == 0) {
         // symbol number j in (length, symbol) order has the canonical code first[l] + (j - start[l])
-        for (uint32_t j = lane; j < L.build_n; j += 64) {
+        for (uint32_t j = lane; j < o; j += 64) {
             const uint32_t s2 = sorted[j], l = lens[s2];
             if (l <= tbits) {
                 const uint32_t code = (uint32_t)L.work_first[l] + (j - L.work_start[l]), rev = __brev(code) >> (32 - l), e = make_entry(kind, s2, l);
