@@ -179,6 +179,141 @@ __device__ int build_tree(TW &t, int elems, int kind, int max_length,
     return max_code;
 }
 
+// build_tree for a whole wave (round 2): the heap stays one lane's -- zlib's order of leaving it decides code lengths (see above) -- but what stands
+// in front of it and behind it is every lane's: the heap is filled by ballot compaction, the depths of the finished tree come from pointer
+// jumping (dad[] doubles as the ancestor at distance 2^k, len[] as the distance: six rounds reach depth 64, a tree over 16 383 tokens is
+// no deeper than 21), counts per length and the cost sums are LDS atomics and a wave reduction, a symbol's code is the first code of its
+// length plus its rank among the symbols of that length (ballots).  Same results as build_tree; every lane returns them.
+__device__ inline uint32_t wave_sum(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o); return v; }
+template <class TW>
+__device__ int build_tree_wave(TW &t, int elems, int kind, int max_length, uint16_t *out_code, uint8_t *out_len, uint32_t &opt_len, uint32_t &static_len, uint32_t lane)
+{
+    constexpr int kGroups = (TW::kCap / 2 + 63) / 64; // symbols: at most (kCap - 1) / 2
+    constexpr int kNodeRounds = (TW::kCap + 63) / 64; // nodes per lane
+    auto sync = [&]() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    int heap_len = 0, max_code = -1;
+#pragma unroll
+    for (int g = 0; g < kGroups; g++) {
+        const int n = g * 64 + (int)lane;
+        const uint32_t f = n < elems ? t.freq[n] : 0u;
+        const uint64_t m = __ballot(f != 0);
+        if (f) t.heap[heap_len + 1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = heap_entry(f, 0, (uint32_t)n);
+        else if (n < elems) t.len[n] = 0;
+        heap_len += (int)__builtin_popcountll(m);
+        if (m) max_code = g * 64 + 63 - (int)__builtin_clzll(m);
+    }
+    sync();
+    int heap_max = TW::kCap, node = elems;
+    if (lane == 0) { // ---- one lane: trees.c:629-669 ----
+        const bool has_static = kind != 2;
+        while (heap_len < 2) {
+            const int nn = max_code < 2 ? ++max_code : 0;
+            t.heap[++heap_len] = heap_entry(1, 0, (uint32_t)nn);
+            t.freq[nn] = 1; opt_len--;
+            if (has_static) static_len -= static_len_of(kind, nn);
+        }
+        for (int n = heap_len / 2; n >= 1; n--) sift_down(t, heap_len, n);
+        do {
+            const uint32_t en = t.heap[1];
+            t.heap[1] = t.heap[heap_len--]; sift_down(t, heap_len, 1);
+            const uint32_t em = t.heap[1];
+            const int n = (int)(en & 1023u), m = (int)(em & 1023u);
+            t.heap[--heap_max] = (uint32_t)n; t.heap[--heap_max] = (uint32_t)m;
+            const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
+            t.dad[n] = t.dad[m] = (uint16_t)node;
+            t.heap[1] = heap_entry((en >> 16) + (em >> 16), (dn >= dm ? dn : dm) + 1, (uint32_t)node);
+            node++;
+            sift_down(t, heap_len, 1);
+        } while (heap_len >= 2);
+        t.heap[--heap_max] = t.heap[1] & 1023u;
+        for (int bits = 0; bits <= kMaxBits; bits++) t.bl_count[bits] = 0;
+        const uint32_t root = t.heap[heap_max];
+        t.len[root] = 0; t.dad[root] = (uint16_t)root;
+    }
+    heap_max = __builtin_amdgcn_readfirstlane(heap_max); max_code = __builtin_amdgcn_readfirstlane(max_code);
+    opt_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)opt_len); static_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)static_len);
+    sync();
+    // ---- gen_bitlen (trees.c:490-567): depth of every node below the root ----
+    uint32_t nd[kNodeRounds];
+    const int first_h = heap_max + 1, nnodes = TW::kCap - first_h;
+#pragma unroll
+    for (int r = 0; r < kNodeRounds; r++) { const int i = r * 64 + (int)lane; nd[r] = i < nnodes ? t.heap[first_h + i] : 0xffffu; if (i < nnodes) t.len[nd[r]] = 1; }
+    sync();
+    for (int round = 0; round < 6; round++) {
+        uint32_t pk[kNodeRounds]; // new distance | new ancestor << 16
+#pragma unroll
+        for (int r = 0; r < kNodeRounds; r++) {
+            pk[r] = 0;
+            if (nd[r] != 0xffffu) { const uint32_t a = t.dad[nd[r]]; pk[r] = ((uint32_t)t.len[nd[r]] + t.len[a]) | ((uint32_t)t.dad[a] << 16); }
+        }
+        sync(); // every lane has read what it needs of this round before anybody writes
+#pragma unroll
+        for (int r = 0; r < kNodeRounds; r++) if (nd[r] != 0xffffu) { t.len[nd[r]] = (uint16_t)pk[r]; t.dad[nd[r]] = (uint16_t)(pk[r] >> 16); }
+        sync();
+    }
+    uint32_t over = 0, osum = 0, ssum = 0;
+#pragma unroll
+    for (int r = 0; r < kNodeRounds; r++) {
+        if (nd[r] == 0xffffu) continue;
+        const int n = (int)nd[r];
+        uint32_t bits = t.len[n];
+        if (bits > (uint32_t)max_length) { bits = (uint32_t)max_length; over++; t.len[n] = (uint16_t)bits; }
+        if (n > max_code) continue; // not a leaf
+        atomicAdd(reinterpret_cast<unsigned int *>(&t.bl_count[bits & ~1u]), 1u << ((bits & 1u) * 16)); // (two 16-bit counts per word)
+        const uint32_t xb = (kind != 0 || n >= 257) ? extra_bits_of(kind, n) : 0u;
+        osum += (uint32_t)t.freq[n] * (bits + xb);
+        if (kind != 2) ssum += (uint32_t)t.freq[n] * (static_len_of(kind, n) + xb);
+    }
+    const int overflow = (int)wave_sum(over);
+    opt_len += wave_sum(osum); static_len += wave_sum(ssum);
+    sync();
+    if (overflow > 0) { // (rare: a code longer than max_length; the repair walks the nodes in the heap's order)
+        if (lane == 0) {
+            int ov = overflow, bits, h = TW::kCap;
+            do {
+                bits = max_length - 1;
+                while (t.bl_count[bits] == 0) bits--;
+                t.bl_count[bits]--; t.bl_count[bits + 1] += 2; t.bl_count[max_length]--;
+                ov -= 2;
+            } while (ov > 0);
+            for (bits = max_length; bits != 0; bits--) {
+                int n = t.bl_count[bits];
+                while (n != 0) {
+                    const int m = (int)t.heap[--h];
+                    if (m > max_code) continue;
+                    if (t.len[m] != (unsigned)bits) {
+                        opt_len += ((uint32_t)bits - (uint32_t)t.len[m]) * (uint32_t)t.freq[m];
+                        t.len[m] = (uint16_t)bits;
+                    }
+                    n--;
+                }
+            }
+        }
+        opt_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)opt_len);
+        sync();
+    }
+    // ---- gen_codes (trees.c:577-609) ----
+    uint32_t nc[kMaxBits + 1], c = 0;
+    nc[0] = 0;
+#pragma unroll
+    for (int bits = 1; bits <= kMaxBits; bits++) { c = (c + t.bl_count[bits - 1]) << 1; nc[bits] = c; }
+#pragma unroll
+    for (int g = 0; g < kGroups; g++) {
+        const int n = g * 64 + (int)lane;
+        const uint32_t l = (n < elems && n <= max_code) ? t.len[n] : 0u;
+        uint32_t code = 0;
+#pragma unroll
+        for (int bits = 1; bits <= kMaxBits; bits++) {
+            const uint64_t m = __ballot(l == (uint32_t)bits);
+            if (l == (uint32_t)bits) code = nc[bits] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            nc[bits] += (uint32_t)__builtin_popcountll(m);
+        }
+        if (n < elems) { out_len[n] = (uint8_t)l; out_code[n] = l ? (uint16_t)(__brev(code) >> (32 - l)) : 0; }
+    }
+    sync();
+    return max_code;
+}
+
 // scan_tree (kEmit false: count into blfreq) / send_tree (kEmit true), trees.c:707-797.  Inlined, the writer by reference: a
 // writer whose address is passed to a real call lives in scratch memory, and every put() is then a trip to HBM and back.
 template <bool kEmit>
@@ -350,14 +485,14 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         __syncthreads();
         HUF_T(0);
         // ---- trees ----
-        if (tid == 0) {
+        if (tid < 64) { // wave 0: the literal/length tree; wave 1: the distance tree
             uint32_t o = 0, s = 0;
-            sh_lmax = (uint32_t)build_tree(work0, kLCodes, 0, kMaxBits, lcode, llen, o, s);
-            sh_optl = o; sh_statl = s;
-        } else if (tid == 64) {
+            const int mc = build_tree_wave(work0, kLCodes, 0, kMaxBits, lcode, llen, o, s, tid);
+            if (tid == 0) { sh_lmax = (uint32_t)mc; sh_optl = o; sh_statl = s; }
+        } else {
             uint32_t o = 0, s = 0;
-            sh_dmax = (uint32_t)build_tree(work1, kDCodes, 1, kMaxBits, dcode, dlen, o, s);
-            sh_optd = o; sh_statd = s;
+            const int mc = build_tree_wave(work1, kDCodes, 1, kMaxBits, dcode, dlen, o, s, tid - 64);
+            if (tid == 64) { sh_dmax = (uint32_t)mc; sh_optd = o; sh_statd = s; }
         }
         __syncthreads();
         HUF_T(1);
