@@ -272,3 +272,38 @@ print("GZIP", hashlib.sha256(zs).hexdigest(), len(zs), info["adler"])
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append([ln for ln in p.stdout.splitlines() if ln.startswith(("ZLIB", "GZIP"))])
     assert len(outs[0]) == 2 and outs[1] == outs[0] and outs[2] == outs[0], outs
+
+
+def test_threads_share_a_pool_of_engines():
+    """ZAMD_ENGINES=3: calls of different threads run side by side on engines of their own (with the default they take turns).  Six threads compress and
+    decompress different buffers at once; every result must be what the same call gives alone."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import hashlib, os, sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import zhost as Z
+from oracle import corpus_py as CP
+bufs = [CP.chunks(k & 1, 50 * k, 200 + 13 * k).tobytes()[: (200 + 13 * k) * 65536 - 1000 * k] for k in range(6)]
+alone = []
+for b in bufs:
+    rc, z = Z.compress2(b, 6); assert rc == 0
+    alone.append(hashlib.sha256(z).hexdigest())
+got, back = [None] * 6, [None] * 6
+def work(i):
+    for _ in range(3):
+        rc, z = Z.compress2(bufs[i], 6); assert rc == 0
+        got[i] = hashlib.sha256(z).hexdigest()
+        rc, out = Z.uncompress(z, len(bufs[i])); assert rc == 0
+        back[i] = out == bufs[i]
+th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+[t.start() for t in th]; [t.join() for t in th]
+assert got == alone and all(back), (got, alone, back)
+print("POOL OK")
+"""
+    for n in ("1", "3"):
+        env = dict(os.environ, ZAMD_ENGINES=n)
+        p = subprocess.run([sys.executable, "-c", child % (ROOT, ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "POOL OK" in p.stdout, p.stderr[-2000:]

@@ -48,6 +48,44 @@ static zgpu_engine *engine_get(void)
     return e;
 }
 
+/* ---- several streams at once: every engine call needs an engine to itself (one stream, one workspace).  ZAMD_ENGINES=n (1..8, default 1) lets up to n
+ * calls of different threads run side by side on engines of their own (created when first needed, on the device of engine_get()); with the default
+ * the calls take turns, as before. ---- */
+#define ZAMD_MAX_ENGINES 8
+static zgpu_engine *g_pool[ZAMD_MAX_ENGINES];
+static int g_pool_busy[ZAMD_MAX_ENGINES], g_pool_made, g_pool_max;
+static pthread_cond_t g_pool_cv = PTHREAD_COND_INITIALIZER;
+
+static zgpu_engine *engine_checkout(void)
+{
+    zgpu_engine *first = engine_get();
+    if (!first) return NULL;
+    pthread_mutex_lock(&g_lock);
+    if (g_pool_max == 0) {
+        const char *v = getenv("ZAMD_ENGINES");
+        long n = v ? strtol(v, NULL, 10) : 1;
+        g_pool_max = n < 1 ? 1 : n > ZAMD_MAX_ENGINES ? ZAMD_MAX_ENGINES : (int)n;
+        g_pool[0] = first; g_pool_made = 1;
+    }
+    for (;;) {
+        for (int i = 0; i < g_pool_made; i++) if (!g_pool_busy[i]) { g_pool_busy[i] = 1; zgpu_engine *e = g_pool[i]; pthread_mutex_unlock(&g_lock); return e; }
+        if (g_pool_made < g_pool_max) {
+            const char *dev = getenv("ZAMD_DEVICE");
+            zgpu_engine *e = NULL;
+            if (zgpu_engine_create(dev ? atoi(dev) : 0, &e) == ZGPU_OK) { g_pool[g_pool_made] = e; g_pool_busy[g_pool_made++] = 1; pthread_mutex_unlock(&g_lock); return e; }
+            g_pool_max = g_pool_made; /* (no room for another one: the ones there are take turns) */
+        }
+        pthread_cond_wait(&g_pool_cv, &g_lock);
+    }
+}
+static void engine_checkin(zgpu_engine *e)
+{
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < g_pool_made; i++) if (g_pool[i] == e) g_pool_busy[i] = 0;
+    pthread_cond_signal(&g_pool_cv);
+    pthread_mutex_unlock(&g_lock);
+}
+
 /* ---- more than one GPU: ZAMD_DEVICES="0,1,2,3" names the devices one deflate() / compress2() call may use.  Chunks are
  * independent, so a large input is cut into contiguous chunk ranges, one per device, each compressed by that device's engine from a thread
  * of its own (no exchange between the devices: the ranges' streams are laid end to end on the host, only the last one carries the final
@@ -432,19 +470,18 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
             if (!stored_chunks(&s->out, src, take, first_final)) return Z_MEM_ERROR;
             s->adler = (uint32_t)adler32(s->adler, src, (uInt)take);
         } else {
-            zgpu_engine *e = engine_get();
-            if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
+            if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
             bytebuf w = {0};
             if (!buf_put(&w, s->dict.p, s->dict.len) || !buf_put(&w, src, take)) { free(w.p); return Z_MEM_ERROR; }
             const uint64_t cap = zgpu_deflate_bound(w.len, CHUNK);
             if (!buf_reserve(&s->out, cap)) { free(w.p); return Z_MEM_ERROR; }
             zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, 0};
             zgpu_deflate_result r;
-            pthread_mutex_lock(&g_lock);
+            zgpu_engine *e = engine_checkout();
             zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
             int rc = zgpu_deflate_dict_chunk_host(e, w.p, (uint32_t)w.len, (uint32_t)s->dict.len, &p, s->out.p + s->out.len, cap, &r);
             zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
-            pthread_mutex_unlock(&g_lock);
+            engine_checkin(e);
             free(w.p);
             if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
             s->out.len += r.out_bytes;
@@ -506,11 +543,11 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
     zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
     zgpu_deflate_result r;
-    pthread_mutex_lock(&g_lock);
+    e = engine_checkout();
     zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
     int rc = zgpu_deflate_host(e, src, n, &p, s->out.p + s->out.len, cap, NULL, &r);
     zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
-    pthread_mutex_unlock(&g_lock);
+    engine_checkin(e);
     if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
     s->out.len += r.out_bytes;
     s->adler = adler_join(s->adler, r.adler32, n); /* computed on the GPU with the chunks (deflate.c:968-970) */
@@ -785,11 +822,11 @@ static int decode_some(z_streamp strm, size_t out_hint)
         if (!buf_reserve(&s->out, cap)) { free(shifted); return Z_MEM_ERROR; }
         memset(&r, 0, sizeof r);
         const int first = s->produced == 0 && s->have_dict; /* the dictionary is what the window holds in front of the first byte only */
-        pthread_mutex_lock(&g_lock);
+        e = engine_checkout();
         int rc = zgpu_inflate_set_dictionary(e, first ? s->dict.p : NULL, first ? (uint32_t)s->dict.len : 0u);
         if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host2(e, src, srcn, ZGPU_INF_STREAM, s->out.p + s->out.len, cap, &r);
         if (first) zgpu_inflate_set_dictionary(e, NULL, 0);
-        pthread_mutex_unlock(&g_lock);
+        engine_checkin(e);
         if (rc == ZGPU_BUF_ERROR) { cap = r.out_bytes > cap ? (size_t)r.out_bytes : cap * 4; if (cap > ((size_t)1 << 40)) { free(shifted); return Z_MEM_ERROR; } continue; }
         free(shifted);
         if (rc == ZGPU_DATA_ERROR) return in_bad(strm, zgpu_inflate_message(r.error_msg));
