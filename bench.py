@@ -287,14 +287,14 @@ def main():
         # the zlib-API path hands over host buffers: H2D of the input, the same kernels, D2H of the stream (SURVEY.md 8d "end-to-end")
         import ctypes as C
         import numpy as np
-        host_n = min(nbytes, 1 << 30)
+        host_n = nbytes  # (the headline's workload: the two rates are of the same bytes)
         host_in = src[:host_n].cpu().numpy()
         host_cap = eng.L.zgpu_deflate_bound(host_n, 65536)
         host_out = np.zeros(host_cap, dtype=np.uint8)  # (touched: the timed call does not pay for page faults of a fresh allocation)
         hp = gpu._Params(a.level, 65536, gpu.F_FINAL | gpu.F_ZLIB_WRAP, gpu.LZ_AUTO, 0, 0)
         hres = gpu.DeflateResult()
         best = None
-        for _ in range(2):  # the second call finds the engine's staging buffers allocated
+        for _ in range(3):  # the second call finds the engine's staging buffers allocated
             t0 = time.perf_counter()
             rc = eng.L.zgpu_deflate_host(eng.h, host_in.ctypes.data, host_n, C.byref(hp), host_out.ctypes.data, host_cap, None, C.byref(hres))
             d = time.perf_counter() - t0
@@ -303,7 +303,8 @@ def main():
             best = d if best is None or d < best else best
         extra["end_to_end_host_buffers"] = {"metric": "GiB/s raw input compressed, host buffers in and out (H2D, kernels, D2H; pageable memory)",
                                             "value": round(host_n / best / 2**30, 4), "unit": "GiB/s", "input_bytes": host_n,
-                                            "stream_bytes": int(hres.out_bytes), "note": "zgpu_deflate_host, best of two calls"}
+                                            "stream_bytes": int(hres.out_bytes), "note": "zgpu_deflate_host, best of three calls",
+                                            "of_resident_rate": round(host_n / best / 2**30 / line["value"], 3)}
         # a stream that was NOT produced in chunks (the system zlib's level-6 output for the first 256 MiB), decoded in pieces at
         # block starts found by search; host buffers in and out (that is how such a stream arrives: uncompress(), inflate(), a zip member)
         import zlib as syszlib

@@ -266,7 +266,15 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // h_dst: what the batches so far have produced goes to the caller's buffer while the next ones are compressed.  Copies to pageable memory
     // hold the calling thread, so they are a second thread's: it waits for batch k's event, reads the stream length behind it (pinned)
     // and copies the new bytes on a stream of its own.
-    const size_t nbatches = (size_t)((nchunks + batch - 1) / batch);
+    // host input, several batches: nothing runs under the first one's copy, so it is a quarter of the others and the second a half -- a copy moves
+    // a chunk 2.3 times as fast as the kernels compress one, so each batch's copy still ends under the kernels of the batch before it -- and what
+    // the short launches cost the latency-bound kernels (see above) is less than what the shorter wait saves (1 GiB: 58.3 -> 55.5 ms with the quarter alone)
+    uint32_t first_div = env_u32("ZGPU_FIRST_BATCH_DIV", 4); // (1: all batches alike, for A/B runs)
+    if (first_div == 0 || first_div > 64) first_div = 4;
+    const uint32_t first = (h_src && nchunks > batch && batch >= 4096) ? batch / first_div : batch;
+    auto next_step = [batch](uint32_t s) { return s >= batch / 2 ? batch : s * 2; };
+    size_t nbatches = 0;
+    for (uint64_t c0 = 0, step = first; c0 < nchunks; c0 += step, step = next_step((uint32_t)step)) nbatches++;
     std::thread homer;
     std::atomic<size_t> issued{0};
     std::atomic<int> homer_rc{0};
@@ -297,8 +305,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         });
     }
     size_t nbatch = 0;
-    for (uint64_t c0 = 0; c0 < nchunks; c0 += batch, nbatch++) {
-        const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+    for (uint64_t c0 = 0, step = first; c0 < nchunks; c0 += step, step = next_step((uint32_t)step), nbatch++) {
+        const uint32_t nb = (uint32_t)(nchunks - c0 < step ? nchunks - c0 : step);
         g.chunk0 = c0; g.nchunks = nb;
         if (h_src && in_bytes) { // this batch's input: host -> device on the copy stream, the kernels below wait for it
             const uint64_t lo = c0 * chunk_size, hi = (c0 + nb) * (uint64_t)chunk_size < in_bytes ? (c0 + nb) * (uint64_t)chunk_size : in_bytes;
