@@ -164,6 +164,14 @@ def test_foreign_archive_and_crc_damage(L, tmp_path):
     liar.write_bytes(bytes(raw))
     got = read_zip(L, liar)
     assert got[0][1] == -103 and got[3][2] == members[3][1]
+    # a directory that announces fewer bytes than the member decodes to (with room for exactly what it announces): a bad file, not a hang
+    raw = bytearray(p.read_bytes())
+    cd = raw.find(b"PK\x01\x02")
+    raw[cd + 24:cd + 28] = (100).to_bytes(4, "little")
+    short = tmp_path / "short.zip"
+    short.write_bytes(bytes(raw))
+    got = read_zip(L, short)
+    assert got[0][1] in (-103, -105) and got[3][2] == members[3][1]
     # not an archive
     junk = tmp_path / "junk.zip"
     junk.write_bytes(b"PK" + bytes(100))

@@ -226,8 +226,10 @@ EXPORT long zamd_unzip_read(zamd_unzip *u, int i, void *out, unsigned long cap)
         const unsigned long out_now = cap - opos > 0xFFFFFFFFul ? 0xFFFFFFFFul : cap - opos;
         s.next_in = gz + ipos; s.avail_in = (uInt)in_now; s.next_out = (Bytef *)out + opos; s.avail_out = (uInt)out_now;
         rc = inflate(&s, ipos + in_now == glen ? Z_FINISH : Z_NO_FLUSH);
+        const int moved = s.avail_in != in_now || s.avail_out != out_now;
         ipos += in_now - s.avail_in; opos += out_now - s.avail_out;
-        if (rc == Z_BUF_ERROR && ipos < glen) rc = Z_OK;
+        if (rc == Z_BUF_ERROR && ipos < glen && moved) rc = Z_OK; /* (no progress: more data than the directory announced -- out of the loop, a bad file) */
+        if (rc == Z_OK && !moved) rc = Z_BUF_ERROR;
     }
     inflateEnd(&s);
     free(gz);
