@@ -326,7 +326,6 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
-            ZGPU_HIP_CHECK(hipMemsetAsync(e->slots, 0, (size_t)nb * kSlotStride, st));
             launch_huffman(g, e->tokens, e->meta, e->slots, st, cfg.strategy == kFixed);
         }
         {

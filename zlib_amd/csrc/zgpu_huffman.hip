@@ -46,30 +46,28 @@ using TreeWork = TreeWorkT<kHeapSize>;          // literal/length tree, and the 
 using TreeWorkD = TreeWorkT<2 * kDCodes + 1>;    // distance tree: a tenth of the LDS, so more chunks are resident per CU
 __device__ inline uint32_t heap_entry(uint32_t freq, uint32_t depth, uint32_t node) { return (freq << 16) | (depth << 10) | node; }
 
-// LSB-first bit writer into a zero-initialised word buffer.
+// LSB-first bit writer.  The buffer is written once, a whole word at a time, and never read: the bits of the word a writer stops in travel to the
+// next writer as its `carry` (the workgroup's writers take turns: block header, token rounds, stored bytes, the chunk's end), so the slots need no
+// zero-initialisation and no atomic OR.
 struct BitWriter {
     uint32_t *words;
     uint32_t wi;    // index of the word being assembled
-    uint64_t acc;   // bits not yet stored (low nacc bits valid)
+    uint64_t acc;   // bits not yet stored (low nacc bits valid, the rest zero)
     uint32_t nacc;
-    bool first;     // the word at wi may be shared with an earlier writer
-    __device__ void begin(uint32_t *base, uint64_t bitpos) { words = base; wi = (uint32_t)(bitpos >> 5); nacc = (uint32_t)(bitpos & 31); acc = 0; first = true; }
+    __device__ void begin(uint32_t *base, uint64_t bitpos, uint32_t carry) { words = base; wi = (uint32_t)(bitpos >> 5); nacc = (uint32_t)(bitpos & 31); acc = carry; }
     __device__ uint64_t pos() const { return ((uint64_t)wi << 5) + nacc; }
     __device__ void put(uint32_t v, uint32_t nb)
     {
         acc |= (uint64_t)v << nacc; nacc += nb;
-        if (nacc >= 32) {
-            uint32_t w = (uint32_t)acc;
-            if (first) { atomicOr(&words[wi], w); first = false; } else words[wi] = w;
-            wi++; acc >>= 32; nacc -= 32;
-        }
+        if (nacc >= 32) { words[wi] = (uint32_t)acc; wi++; acc >>= 32; nacc -= 32; }
     }
     __device__ void put64(uint64_t v, uint32_t nb)
     {
         if (nb > 32) { put((uint32_t)v, 32); put((uint32_t)(v >> 32), nb - 32); } else put((uint32_t)v, nb);
     }
     __device__ void align_byte() { uint32_t k = (8 - (nacc & 7)) & 7; if (k) put(0, k); }
-    __device__ void finish() { if (nacc) atomicOr(&words[wi], (uint32_t)acc); nacc = 0; acc = 0; }
+    __device__ uint32_t carry() const { return (uint32_t)acc; } // the bits of the unfinished word, for the writer that goes on at pos()
+    __device__ void store_tail() { if (nacc) words[wi] = (uint32_t)acc; } // the last writer of a slot
 };
 
 template <class TW>
@@ -437,6 +435,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     uint32_t *tokbuf = reinterpret_cast<uint32_t *>(&work0), *obuf = tokbuf + kEmitRound;
     __shared__ uint32_t sh_optl, sh_statl, sh_optd, sh_statd, sh_btype, sh_lmax, sh_dmax;
     __shared__ uint64_t sh_bitpos;
+    __shared__ uint32_t sh_carry; // the bits of the word at sh_bitpos that are not in memory yet (BitWriter)
 
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     if (c >= g.nchunks) return;
@@ -449,7 +448,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
     const bool final_chunk_here = chunk_is_final(g, c);
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
-    if (tid == 0) sh_bitpos = 0;
+    if (tid == 0) { sh_bitpos = 0; sh_carry = 0; }
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
@@ -518,7 +517,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             sh_btype = btype;
             HUF_T(2);
             // ---- block header ----
-            BitWriter bw; bw.begin(out, sh_bitpos);
+            BitWriter bw; bw.begin(out, sh_bitpos, sh_carry);
             bw.put((btype << 1) + eof, 3);
             if (btype == 0) {
                 bw.align_byte(); bw.put(stored_len & 0xffff, 16); bw.put(~stored_len & 0xffff, 16);
@@ -529,7 +528,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
                 walk_lengths<true>(dlen, dmax, nullptr, bw, blcode, bllen);
             }
             sh_bitpos = bw.pos();
-            bw.finish();
+            sh_carry = bw.carry();
         }
         __syncthreads();
         HUF_T(3);
@@ -537,6 +536,10 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         uint64_t bitpos = sh_bitpos;
         if (btype == 0) {
             uint8_t *dst = reinterpret_cast<uint8_t *>(out) + (bitpos >> 3);
+            if (tid == 0) { // the header's last bytes, still in the carry (the stored bytes follow them inside the same word)
+                const uint32_t k = (uint32_t)(bitpos >> 3) & 3u, cw = sh_carry;
+                for (uint32_t j = 0; j < k; j++) dst[(int)j - (int)k] = (uint8_t)(cw >> (8 * j));
+            }
             for (uint32_t i = tid; i < stored_len; i += kThreads) dst[i] = src[block_start + i];
             bitpos += (uint64_t)stored_len * 8;
         } else {
@@ -547,7 +550,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
             }
             // Rounds of kEmitRound tokens (the end-of-block code is the token behind the last): read coalesced into LDS, kEmitPer consecutive ones
             // per lane sized and coded once, a prefix scan for the bit offsets, the bits put together in LDS (ds_or), the round's words stored
-            // coalesced -- the first and the last, shared with what lies in front and behind, by atomic OR (the slot is zero-initialised).
+            // coalesced; the bits of the word the round stops in stay behind as the carry of the next round (or of the next writer).
             for (uint32_t i = tid; i < kObufWords; i += kThreads) obuf[i] = 0; // (the first round's barrier stands between this and the first bits)
             for (uint32_t r0 = 0; r0 <= nt; r0 += kEmitRound) {
                 uint32_t tv[kEmitPer];
@@ -556,6 +559,7 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
 #pragma unroll
                 for (uint32_t k = 0; k < kEmitPer; k++) tokbuf[k * kThreads + tid] = tv[k];
                 __syncthreads();
+                if (tid == 0) obuf[0] = sh_carry; // what the writer before this round left of its last word (lane 0 cleared the word; the scan's barriers stand before the round's bits)
                 const uint4 mine = reinterpret_cast<const uint4 *>(tokbuf)[tid];
                 const uint32_t mt[4] = {mine.x, mine.y, mine.z, mine.w};
                 uint64_t v[kEmitPer]; uint32_t nb[kEmitPer], mybits = 0;
@@ -581,28 +585,35 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
                     at += nb[k];
                 }
                 __syncthreads();
-                const uint32_t nwords = (sh0 + total + 31) >> 5;
+                const uint32_t nfull = (sh0 + total) >> 5, nwords = (sh0 + total + 31) >> 5;
                 uint32_t *dstw = out + (bitpos >> 5);
                 for (uint32_t w = tid; w < nwords; w += kThreads) {
                     const uint32_t x = obuf[w];
                     obuf[w] = 0;
-                    if (w == 0 || w + 1 == nwords) { if (x) atomicOr(&dstw[w], x); } else dstw[w] = x;
+                    if (w < nfull) dstw[w] = x; else sh_carry = x; // (one lane at most: the word the round stops in)
                 }
+                if (tid == 0 && nfull == nwords) sh_carry = 0;
                 bitpos += total;
             }
         }
         block_start += stored_len;
         __syncthreads();
         HUF_T(4);
-        if (tid == 0) sh_bitpos = bitpos;
+        if (tid == 0) {
+            sh_bitpos = bitpos;
+            if (btype == 0) { // the stored bytes that share their word with what follows: back from memory (this workgroup wrote them in front of the barrier)
+                const uint32_t k = (uint32_t)(bitpos >> 3) & 3u;
+                sh_carry = k ? *reinterpret_cast<volatile uint32_t *>(out + (bitpos >> 5)) & ((1u << (8 * k)) - 1u) : 0u;
+            }
+        }
         __syncthreads();
     }
     if (tid == 0) {
-        BitWriter bw; bw.begin(out, sh_bitpos);
+        BitWriter bw; bw.begin(out, sh_bitpos, sh_carry);
         if (!final_chunk_here) { bw.put(0, 3); bw.align_byte(); bw.put(0, 16); bw.put(0xffff, 16); } // flush marker
         else bw.align_byte();                                                                        // bi_windup
         uint64_t endpos = bw.pos();
-        bw.finish();
+        bw.store_tail();
         meta[c].out_bytes = (uint32_t)(endpos >> 3);
         meta[c].data_type = data_type;
     }
