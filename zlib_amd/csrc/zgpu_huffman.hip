@@ -341,6 +341,90 @@ __device__ __forceinline__ void walk_lengths(const uint8_t *len, int max_code, u
     }
 }
 
+// scan_tree / send_tree for a whole wave.  The state machine above depends on nothing but the run of equal lengths it stands in: a run of zeros is
+// cut into pieces of 138 (REPZ_11_138) and what is left is REPZ_11_138 / REPZ_3_10 / one or two zeros; a run of a length L is L, REP_3_6 of up to 6
+// for the first seven (four to seven: L and a repeat; fewer: literals), then REP_3_6 of 6 as long as six are left, then a repeat of 3..5 or one
+// or two literals (trees.c:721-741: max_count / min_count 138/3 inside zeros, 7/4 at the start of a run, 6/3 inside it).  So the runs are found
+// by ballot, compacted (one lane per run), and every lane plays its run's pieces: MODE 0 counts the symbols of the bit-length alphabet (LDS atomics),
+// MODE 1 returns the bits the run's items take, MODE 2 ORs them into `obuf` at bit offset `at`.
+template <int MODE>
+__device__ __forceinline__ uint32_t run_items(uint32_t L, uint32_t N, uint32_t *blf, const uint16_t *blcode, const uint8_t *bllen, uint32_t *obuf, uint32_t at)
+{
+    uint32_t bits = 0, rem = N;
+    bool first = true;
+    auto item = [&](uint32_t sym, uint32_t xv, uint32_t xb) {
+        if (MODE == 0) atomicAdd(&blf[sym], 1u);
+        else {
+            const uint32_t cl = bllen[sym], nb = cl + xb;
+            if (MODE == 2) {
+                const uint32_t v = (uint32_t)blcode[sym] | (xv << cl), w = at >> 5, sh = at & 31; // 14 bits at most
+                atomicOr(&obuf[w], v << sh);
+                if (sh + nb > 32) atomicOr(&obuf[w + 1], v >> (32 - sh));
+                at += nb;
+            }
+            bits += nb;
+        }
+    };
+    while (rem) {
+        if (L == 0) {
+            const uint32_t take = rem < 138 ? rem : 138;
+            if (take < 3) { for (uint32_t k = 0; k < take; k++) item(0, 0, 0); }
+            else if (take <= 10) item(17, take - 3, 3);
+            else item(18, take - 11, 7);
+            rem -= take;
+        } else {
+            const uint32_t maxc = first ? 7 : 6, minc = first ? 4 : 3, take = rem < maxc ? rem : maxc;
+            if (take < minc) { for (uint32_t k = 0; k < take; k++) item(L, 0, 0); }
+            else if (first) { item(L, 0, 0); item(16, take - 4, 2); }
+            else item(16, take - 3, 2);
+            rem -= take; first = false;
+        }
+    }
+    return bits;
+}
+
+// the runs of len[0..max_code], compacted into spos[] (start positions, spos[nruns] = max_code + 1); returns nruns.  One wave.
+__device__ __forceinline__ uint32_t find_runs(const uint8_t *len, int max_code, uint16_t *spos, uint32_t lane)
+{
+    uint32_t nruns = 0;
+    for (int g = 0; g * 64 <= max_code; g++) {
+        const int n = g * 64 + (int)lane;
+        const bool valid = n <= max_code;
+        const uint32_t cur = valid ? len[n] : 0u, prv = (valid && n > 0) ? len[n - 1] : 0u;
+        const bool st = valid && (n == 0 || cur != prv);
+        const uint64_t m = __ballot(st);
+        if (st) spos[nruns + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)n;
+        nruns += (uint32_t)__builtin_popcountll(m);
+    }
+    if (lane == 0) spos[nruns] = (uint16_t)(max_code + 1);
+    __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return nruns;
+}
+
+// MODE 0: scan_tree into blf[]; MODE 2: send_tree into obuf from bit offset at0 on, returns the bits written.  One wave; spos is scratch.
+template <int MODE>
+__device__ __forceinline__ uint32_t walk_lengths_wave(const uint8_t *len, int max_code, uint16_t *spos, uint32_t *blf, const uint16_t *blcode, const uint8_t *bllen,
+                                                      uint32_t *obuf, uint32_t at0, uint32_t lane)
+{
+    const uint32_t nruns = find_runs(len, max_code, spos, lane);
+    uint32_t done = 0;
+    for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        uint32_t L = 0, N = 0;
+        if (r < nruns) { const uint32_t p = spos[r]; N = (uint32_t)spos[r + 1] - p; L = len[p]; }
+        if (MODE == 0) run_items<0>(L, N, blf, blcode, bllen, obuf, 0);
+        else {
+            const uint32_t mybits = run_items<1>(L, N, blf, blcode, bllen, obuf, 0);
+            uint32_t x = mybits;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
+            run_items<2>(L, N, blf, blcode, bllen, obuf, at0 + done + x - mybits);
+            done += __shfl(x, 63);
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return done;
+}
+
 // Length and distance codes in closed form (the maps behind _length_code / _dist_code / base_length / base_dist / extra_lbits /
 // extra_dbits of trees.h and trees.c:61-68): code and number of extra bits from the position of the leading one; the extra
 // bits' value is the low bits of the length or distance itself, because every code's base is a multiple of its range.
@@ -495,40 +579,64 @@ __global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const
         }
         __syncthreads();
         HUF_T(1);
-        if (tid == 0) {
-            uint32_t opt_len = sh_optl + sh_optd, static_len = sh_statl + sh_statd;
+        if (tid < 64) { // wave 0: the bit-length alphabet, the block type, the header (the other wave waits at the barrier below)
+            const uint32_t lane = tid;
+            auto wsync = [&]() { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
             const int lmax = (int)sh_lmax, dmax = (int)sh_dmax;
+            uint32_t *blf = hist;                                         // (the histogram is dead until the next block clears it)
+            uint16_t *spos = reinterpret_cast<uint16_t *>(hist + 32);     // run starts of a code-length sequence, kLCodes + 1 at most
+            static_assert((kLCodes + kDCodes + 2 - 32) * 2 >= kLCodes + 2, "run starts fit behind the counts");
+            if (lane < kBLCodes) blf[lane] = 0;
+            wsync();
+            walk_lengths_wave<0>(llen, lmax, spos, blf, nullptr, nullptr, nullptr, 0, lane);
+            walk_lengths_wave<0>(dlen, dmax, spos, blf, nullptr, nullptr, nullptr, 0, lane);
             TreeWork &w = work0;
-            for (int i = 0; i < kBLCodes; i++) w.freq[i] = 0;
-            BitWriter none;
-            walk_lengths<false>(llen, lmax, w.freq, none, nullptr, nullptr);
-            walk_lengths<false>(dlen, dmax, w.freq, none, nullptr, nullptr);
-            uint32_t dummy = 0;
-            build_tree(w, kBLCodes, 2, kMaxBLBits, blcode, bllen, opt_len, dummy);
-            int max_blindex;
-            for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--) if (bllen[kTables.bl_order[max_blindex]] != 0) break;
-            opt_len += 3 * (uint32_t)(max_blindex + 1) + 5 + 5 + 4;
-            uint32_t opt_lenb = (opt_len + 3 + 7) >> 3, static_lenb = (static_len + 3 + 7) >> 3;
-            if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
-            uint32_t btype;
-            if (stored_len + 4 <= opt_lenb && !((nostore >> b) & 1)) btype = 0;
-            else if (fixed_trees || static_lenb == opt_lenb) btype = 1; // Z_FIXED: trees.c:986
-            else btype = 2;
-            sh_btype = btype;
-            HUF_T(2);
-            // ---- block header ----
-            BitWriter bw; bw.begin(out, sh_bitpos, sh_carry);
-            bw.put((btype << 1) + eof, 3);
-            if (btype == 0) {
-                bw.align_byte(); bw.put(stored_len & 0xffff, 16); bw.put(~stored_len & 0xffff, 16);
-            } else if (btype == 2) {
-                bw.put((uint32_t)(lmax + 1 - 257), 5); bw.put((uint32_t)(dmax + 1 - 1), 5); bw.put((uint32_t)(max_blindex + 1 - 4), 4);
-                for (int r = 0; r <= max_blindex; r++) bw.put(bllen[kTables.bl_order[r]], 3);
-                walk_lengths<true>(llen, lmax, nullptr, bw, blcode, bllen);
-                walk_lengths<true>(dlen, dmax, nullptr, bw, blcode, bllen);
+            if (lane < kBLCodes) w.freq[lane] = (uint16_t)blf[lane];
+            wsync();
+            if (lane == 0) {
+                uint32_t opt_len = sh_optl + sh_optd, static_len = sh_statl + sh_statd;
+                uint32_t dummy = 0;
+                build_tree(w, kBLCodes, 2, kMaxBLBits, blcode, bllen, opt_len, dummy);
+                int max_blindex;
+                for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--) if (bllen[kTables.bl_order[max_blindex]] != 0) break;
+                opt_len += 3 * (uint32_t)(max_blindex + 1) + 5 + 5 + 4;
+                uint32_t opt_lenb = (opt_len + 3 + 7) >> 3, static_lenb = (static_len + 3 + 7) >> 3;
+                if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+                uint32_t btype;
+                if (stored_len + 4 <= opt_lenb && !((nostore >> b) & 1)) btype = 0;
+                else if (fixed_trees || static_lenb == opt_lenb) btype = 1; // Z_FIXED: trees.c:986
+                else btype = 2;
+                sh_btype = btype;
+                HUF_T(2);
+                // ---- block header: the fixed part ----
+                BitWriter bw; bw.begin(out, sh_bitpos, sh_carry);
+                bw.put((btype << 1) + eof, 3);
+                if (btype == 0) {
+                    bw.align_byte(); bw.put(stored_len & 0xffff, 16); bw.put(~stored_len & 0xffff, 16);
+                } else if (btype == 2) {
+                    bw.put((uint32_t)(lmax + 1 - 257), 5); bw.put((uint32_t)(dmax + 1 - 1), 5); bw.put((uint32_t)(max_blindex + 1 - 4), 4);
+                    for (int r = 0; r <= max_blindex; r++) bw.put(bllen[kTables.bl_order[r]], 3);
+                }
+                sh_bitpos = bw.pos();
+                sh_carry = bw.carry();
             }
-            sh_bitpos = bw.pos();
-            sh_carry = bw.carry();
+            wsync();
+            if (sh_btype == 2) { // ---- the two code-length sequences behind it: every lane its runs, the bits put together in LDS as a round of tokens is ----
+                constexpr uint32_t kHdrWords = (31 + (kLCodes + kDCodes) * 14 + 31) / 32 + 2;
+                static_assert(kHdrWords <= kObufWords, "the header's bits fit the round buffer");
+                const uint64_t pos0 = sh_bitpos;
+                const uint32_t sh0 = (uint32_t)(pos0 & 31);
+                for (uint32_t i = lane; i < kHdrWords; i += 64) obuf[i] = 0;
+                wsync();
+                if (lane == 0) obuf[0] = sh_carry;
+                wsync();
+                uint32_t nbits = walk_lengths_wave<2>(llen, lmax, spos, blf, blcode, bllen, obuf, sh0, lane);
+                nbits += walk_lengths_wave<2>(dlen, dmax, spos, blf, blcode, bllen, obuf, sh0 + nbits, lane);
+                const uint32_t nfull = (sh0 + nbits) >> 5, nwords = (sh0 + nbits + 31) >> 5;
+                uint32_t *dstw = out + (pos0 >> 5);
+                for (uint32_t wd = lane; wd < nwords; wd += 64) { const uint32_t x = obuf[wd]; if (wd < nfull) dstw[wd] = x; else sh_carry = x; }
+                if (lane == 0) { if (nfull == nwords) sh_carry = 0; sh_bitpos = pos0 + nbits; }
+            }
         }
         __syncthreads();
         HUF_T(3);
