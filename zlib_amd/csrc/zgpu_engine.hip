@@ -26,7 +26,7 @@ bool lz_parallel_available();
 size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
+bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
@@ -315,13 +315,14 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipEventRecord(e->copy_ev[nbatch], e->copy_stream));
             ZGPU_HIP_CHECK(hipStreamWaitEvent(st, e->copy_ev[nbatch], 0));
         }
+        bool adler_done = false;
         if (serial) {
             StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
             if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST)
-                launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : 0);
+                adler_done = launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : 0);
             else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {
@@ -330,7 +331,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
-            launch_adler(g, e->meta, st);
+            if (!adler_done) launch_adler(g, e->meta, st); // (the sort of the default path has computed it on the way)
             if (gz || (p->flags & ZGPU_F_CRC32)) launch_crc(g, e->meta, st);
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st, gz || (p->flags & ZGPU_F_CRC32));
             launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);

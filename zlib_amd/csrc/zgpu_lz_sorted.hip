@@ -239,8 +239,12 @@ struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 __device__ inline uint32_t lds_add_rtn32_nowait(uint32_t a, uint32_t v) { uint32_t o; asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(v) : "memory"); return o; }
 
 __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint16_t *__restrict__ rank_all, uint32_t *__restrict__ heads_all,
-                                                           uint32_t *__restrict__ fault, uint32_t *__restrict__ ir_all)
+                                                           uint32_t *__restrict__ fault, uint32_t *__restrict__ ir_all, ChunkMeta *__restrict__ meta)
 {
+    // (the chunk's Adler-32 rides along: pass A has every byte of the chunk in a register once, and the kernel is waiting for the LDS, not for
+    // the vector unit -- a kernel of its own re-read the input for 0.7 ms per 4 GiB)
+    __shared__ uint32_t ad1[kS3Waves];
+    __shared__ uint64_t ad2[kS3Waves];
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kHashSize / 2]; // count of hash h in half (h & 1) of word h >> 1; later the bucket starts
     __shared__ uint32_t wave_tot[kS3Waves];
     __shared__ uint32_t token;
@@ -272,9 +276,14 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     // ---- pass A: rank(p) ----
     {
         uint32_t hv[kS3TurnSteps];
+        uint32_t s1 = 0, s2 = 0; // Adler: sum of this lane's bytes, and of (n - p) * byte (64 positions a lane: below 2^32)
         auto preload = [&](uint32_t T) {
 #pragma unroll
-            for (uint32_t u = 0; u < kS3TurnSteps; u++) { const uint32_t p = T * kS3TurnPos + 64 * u + lane; hv[u] = p < npos ? hash_of(bytes3(p)) : ~0u; }
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                const uint32_t p = T * kS3TurnPos + 64 * u + lane, v = p < npos ? bytes3(p) : 0u;
+                hv[u] = p < npos ? hash_of(v) : ~0u;
+                s1 += v & 255u; s2 += (n - p) * (v & 255u);
+            }
         };
         if (wave < nturns) preload(wave);
 #pragma unroll 1
@@ -299,8 +308,17 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
             }
             if (T + kS3Waves < nturns) preload(T + kS3Waves);
         }
+        uint64_t t2 = s2;
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); t2 += __shfl_down(t2, o); }
+        if (lane == 0) { ad1[wave] = s1; ad2[wave] = t2; }
     }
     __syncthreads();
+    if (tid == 0) { // A = 1 + sum b_i, B = n + sum (n - i) b_i (mod 65521); the last two bytes start no three-byte string and are added here
+        uint64_t a = 1, b = n;
+        for (uint32_t w = 0; w < kS3Waves; w++) { a += ad1[w]; b += ad2[w] % 65521u; }
+        for (uint32_t p = npos; p < n; p++) { a += src[p]; b += (uint64_t)(n - p) * src[p]; }
+        meta[c].adler_a = (uint32_t)(a % 65521u); meta[c].adler_b = (uint32_t)(b % 65521u); meta[c].in_bytes = n;
+    }
     S3_STOP(1);
 
     // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place); 32 consecutive counts per lane ----
@@ -1198,8 +1216,10 @@ __global__ void __launch_bounds__(64) fast_kernel(ChunkGeom g, LevelCfg cfg, con
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
 // `walk`: parse-driven search (walk_kernel + the lite parse) instead of the all-position search (match3_kernel + parse2_kernel)
 // `walk` 2: levels 1-3, deflate_fast on the sorted buckets (fast_kernel)
-void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk)
+// returns true when the sort has left the chunks' Adler-32 in meta[] (sort3_kernel does; the ballot-only sort does not)
+bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk)
 {
+    bool adler_done = false;
     uint8_t *w = static_cast<uint8_t *>(workspace);
     const size_t nch = g.nchunks;
     uint32_t *fault = reinterpret_cast<uint32_t *>(w);
@@ -1217,7 +1237,8 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
         hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
     }
     else {
-        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir);
+        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        adler_done = true;
         if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st); // zgpu_debug_inject_sort_fault(): exercise the engine's fallback without a real fault
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
@@ -1231,7 +1252,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
         if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; } // (measured best at 4 GiB: 16 chunks per wave)
         hipLaunchKernelGGL(fast_kernel, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, S, ir, G, tokens, meta, lanes);
         prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
-        return;
+        return adler_done;
     }
     if (walk) { // the records' memory holds the walkers' output: gm (u32 per position), then the bitmaps gs (2048 words per chunk)
         uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
@@ -1246,14 +1267,14 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
         if (fuse) {
             hipLaunchKernelGGL(walk_kernel<true>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
             prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
-            return;
+            return adler_done;
         }
         hipLaunchKernelGGL(walk_kernel<false>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
         prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
         prof_span_begin(prof, st, &ev);
         launch_parse_lite(g, cfg, gm, gs, tokens, meta, st);
         prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
-        return;
+        return adler_done;
     }
     static bool opt_in3 = false;
     if (!opt_in3) { hipFuncSetAttribute(reinterpret_cast<const void *>(match3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kM3Lds); opt_in3 = true; }
@@ -1262,6 +1283,7 @@ void launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     prof_span_begin(prof, st, &ev);
     launch_parse(g, cfg, recs, tokens, meta, st);
     prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
+    return adler_done;
 }
 
 // the word sort3's pass V raises (first word of the workspace)
