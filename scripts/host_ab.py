@@ -1,5 +1,5 @@
 """GPU box: zgpu_deflate_host (host buffers in and out) at level 6, `GIB` GiB of the Silesia-mix; run once per setting of
-ZGPU_FIRST_BATCH_DIV / ZGPU_BATCH_CHUNKS (the engine reads them per call).  Prints the best of three calls and the resident rate beside it."""
+ZGPU_FIRST_BATCH / ZGPU_HOST_BATCH, given as first:batch in chunks (the engine reads them per call).  Prints the best of three calls and the resident rate beside it."""
 import ctypes as C
 import os
 import sys
@@ -26,10 +26,10 @@ for _ in range(2):
     e.deflate_device(src.data_ptr(), host.size, 6, dst.data_ptr(), cap)
     torch.cuda.synchronize(); res_ms = (time.perf_counter() - t0) * 1e3
 ref = None
-for setting in sys.argv[1:] or ["4:8192"]:
-    div, batch = setting.split(":")
-    os.environ["ZGPU_FIRST_BATCH_DIV"] = div
-    os.environ["ZGPU_BATCH_CHUNKS"] = batch
+for setting in sys.argv[1:] or ["2048:16384"]:
+    first, batch = setting.split(":")
+    os.environ["ZGPU_FIRST_BATCH"] = first
+    os.environ["ZGPU_HOST_BATCH"] = batch
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
@@ -41,5 +41,5 @@ for setting in sys.argv[1:] or ["4:8192"]:
     if ref is None:
         ref = z
     assert z == ref, "stream differs between settings"
-    print("first/%s batch %s: %.1f ms = %.2f GiB/s (resident: %.1f ms = %.2f GiB/s; ratio %.2f)" % (
-        div, batch, best * 1e3, gib / best, res_ms, gib / (res_ms / 1e3), res_ms / 1e3 / best), flush=True)
+    print("first %s batch %s: %.1f ms = %.2f GiB/s (resident: %.1f ms = %.2f GiB/s; ratio %.2f)" % (
+        first, batch, best * 1e3, gib / best, res_ms, gib / (res_ms / 1e3), res_ms / 1e3 / best), flush=True)

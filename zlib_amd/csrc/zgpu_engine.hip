@@ -227,7 +227,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // host input: the copy of batch k+1 runs under the kernels of batch k.  Batches must stay large: the block-construction and sort kernels are
     // latency-bound and need every workgroup slot of the chip filled several times over (2048 chunks per launch: 2.2x the time per byte of
     // 65536, rocprofv3 timeline of scripts/host_trace.py); the copy moves 57 GB/s and is over long before the kernels are
-    if (h_src && batch_max > 8192) batch_max = 8192;
+    const uint32_t host_batch = env_u32("ZGPU_HOST_BATCH", 16384); // (A/B runs; measured at 4 GiB: 8192 184.8 ms, 16384 176.3, 32768 178.5)
+    if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
@@ -266,12 +267,12 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // h_dst: what the batches so far have produced goes to the caller's buffer while the next ones are compressed.  Copies to pageable memory
     // hold the calling thread, so they are a second thread's: it waits for batch k's event, reads the stream length behind it (pinned)
     // and copies the new bytes on a stream of its own.
-    // host input, several batches: nothing runs under the first one's copy, so it is a quarter of the others and the second a half -- a copy moves
-    // a chunk 2.3 times as fast as the kernels compress one, so each batch's copy still ends under the kernels of the batch before it -- and what
-    // the short launches cost the latency-bound kernels (see above) is less than what the shorter wait saves (1 GiB: 58.3 -> 55.5 ms with the quarter alone)
-    uint32_t first_div = env_u32("ZGPU_FIRST_BATCH_DIV", 4); // (1: all batches alike, for A/B runs)
-    if (first_div == 0 || first_div > 64) first_div = 4;
-    const uint32_t first = (h_src && nchunks > batch && batch >= 4096) ? batch / first_div : batch;
+    // host input, several batches: nothing runs under the first one's copy, so it is short (2048 chunks) and the next ones double up to the full
+    // batch -- a copy moves a chunk 2.3 times as fast as the kernels compress one, so each batch's copy still ends under the kernels of the batch
+    // before it -- and what the short launches cost the latency-bound kernels (see above) is less than what the shorter wait saves
+    // (1 GiB: 58.3 -> 55.5 ms; profiles/r02_host_batches_ab.txt)
+    const uint32_t first_env = env_u32("ZGPU_FIRST_BATCH", 2048); // (chunks; 0: all batches alike, for A/B runs)
+    const uint32_t first = (h_src && first_env && batch >= 2 * first_env && nchunks > first_env) ? first_env : batch;
     auto next_step = [batch](uint32_t s) { return s >= batch / 2 ? batch : s * 2; };
     size_t nbatches = 0;
     for (uint64_t c0 = 0, step = first; c0 < nchunks; c0 += step, step = next_step((uint32_t)step)) nbatches++;
