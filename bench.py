@@ -168,6 +168,7 @@ def main():
 
     step = deflate_step
     if a.op == "inflate":
+        eng.inflate_set_checks(gpu.CHECK_ADLER32)  # a zlib stream: the check its trailer holds
         deflate_step()
         res = state["res"]
         # raw body without the 2-byte header: offsets are relative to the stream start, which includes the header
@@ -272,7 +273,11 @@ def main():
 
         def inf():
             state["ires"] = eng.inflate_device(dst.data_ptr(), z_len, offs.data_ptr(), nchunks, src2.data_ptr(), nbytes, stream=stream)
+        eng.inflate_set_checks(gpu.CHECK_ADLER32)  # a zlib stream: the check its trailer holds (as inflate() of the host library asks)
         d, pr = timed(inf, a.steps, 1)
+        eng.inflate_set_checks(gpu.CHECK_ADLER32 | gpu.CHECK_CRC32)
+        if state["ires"].adler32 != state["res"].adler32:
+            sys.exit("inflate: Adler-32 of the output differs from the stream's")
         if not bool(torch.equal(src, src2)):
             sys.exit("inflate output differs from the original input")
         extra["inflate"] = {"metric": "GiB/s raw output decompressed (inflate of the level-%d stream)" % a.level,

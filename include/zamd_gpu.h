@@ -186,6 +186,13 @@ const char *zgpu_inflate_message(uint32_t index);
 /* Preset dictionary of the inflate calls that follow (inflateSetDictionary, qcsrc/inflate.c:1200-1236): the first segment of a
  * call may reach back into its last min(len, 32768) bytes.  Stays set until replaced; len 0 clears it. */
 int zgpu_inflate_set_dictionary(zgpu_engine *e, const void *dict, uint32_t len);
+/* Which checks of the decoded bytes the inflate calls that follow compute into zgpu_inflate_result: ZGPU_CHECK_ADLER32 (what a zlib
+ * stream's trailer holds, qcsrc/inflate.c:1083-1094), ZGPU_CHECK_CRC32 (a gzip member's), both (the default) or none (raw deflate:
+ * inflate() keeps no check there, inflate.c:862-866).  A check that is not computed reads adler32 = 1 / crc32 = 0.  Each one is a pass
+ * over the output (0.7 and 2.5 ms per 4 GiB).  Stays set until replaced. */
+#define ZGPU_CHECK_ADLER32 1u
+#define ZGPU_CHECK_CRC32 2u
+int zgpu_inflate_set_checks(zgpu_engine *e, uint32_t mask);
 
 /* ---- checksums (qcsrc/adler32.c:57-149) ---- */
 int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream);

@@ -198,3 +198,27 @@ def test_segment_rules(eng):
     o2 = np.array([0, len(segs[0]), len(segs[0]) + len(segs[1])], dtype=np.uint64)
     with pytest.raises(zlib_amd.EngineError):
         eng.inflate_host(b"".join(segs), o2, out_len=len(data))
+
+
+def test_checks_of_the_output_can_be_chosen(eng):
+    """zgpu_inflate_set_checks: Adler-32 only (a zlib stream), CRC-32 only (a gzip member), both (the default), none (raw deflate); a check that is
+    not computed reads 1 / 0, the bytes are the same; a mask beyond the two bits is refused; the setting stays until replaced."""
+    import zlib as syszlib
+    from zlib_amd import gpu
+    data = cases.make("text", 300000, 77) + cases.make("rand", 70000, 78)
+    z, offs = eng.deflate_host(data, 6, want_offsets=True)
+    ad, cr = syszlib.adler32(data), syszlib.crc32(data)
+    try:
+        for mask, want in ((gpu.CHECK_ADLER32, (ad, 0)), (gpu.CHECK_CRC32, (1, cr)), (0, (1, 0)), (gpu.CHECK_ADLER32 | gpu.CHECK_CRC32, (ad, cr))):
+            eng.inflate_set_checks(mask)
+            for _ in range(2):
+                assert eng.inflate_host(z, offs, out_len=len(data)) == data
+                assert (eng.last_inflate.adler32, eng.last_inflate.crc32) == want, mask
+            raw = syszlib.compressobj(6, syszlib.DEFLATED, -15)
+            body = raw.compress(data) + raw.flush()
+            assert eng.inflate_stream_host(body, len(data)) == data  # (a stream of another producer: the same pass behind another decoder)
+            assert (eng.last_inflate.adler32, eng.last_inflate.crc32) == want, mask
+        with pytest.raises(Exception):
+            eng.inflate_set_checks(4)
+    finally:
+        eng.inflate_set_checks(gpu.CHECK_ADLER32 | gpu.CHECK_CRC32)

@@ -68,6 +68,7 @@ struct zgpu_engine {
     uint64_t *inf_offs = nullptr; uint64_t inf_offs_cap = 0;
     void *inf_slots = nullptr; uint64_t inf_slots_cap = 0;
     uint8_t *inf_dict = nullptr; uint32_t inf_dict_len = 0; // preset dictionary of the next inflate calls (zgpu_inflate_set_dictionary)
+    uint32_t inf_checks = 3;                                // checks of the decoded bytes (zgpu_inflate_set_checks)
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -595,6 +596,13 @@ int zgpu_inflate_set_dictionary(zgpu_engine *e, const void *dict, uint32_t len)
     return ZGPU_OK;
 }
 
+int zgpu_inflate_set_checks(zgpu_engine *e, uint32_t mask)
+{
+    if (!e || mask > 3u) return fail(e, ZGPU_STREAM_ERROR, "checks: a mask of ZGPU_CHECK_ADLER32 | ZGPU_CHECK_CRC32");
+    e->inf_checks = mask;
+    return ZGPU_OK;
+}
+
 int zgpu_adler32_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, uint32_t *adler_out, void *hip_stream)
 {
     if (!e || !adler_out || (!d_in && in_bytes)) return fail(e, ZGPU_STREAM_ERROR, "null argument");
@@ -705,6 +713,7 @@ uint8_t *engine_stage_in(zgpu_engine *e) { return e->stage_in; }
 uint8_t *engine_stage_out(zgpu_engine *e) { return e->stage_out; }
 const uint8_t *engine_inflate_dict(zgpu_engine *e) { return e->inf_dict; }
 uint32_t engine_inflate_dict_len(zgpu_engine *e) { return e->inf_dict_len; }
+uint32_t engine_inflate_checks(zgpu_engine *e) { return e->inf_checks; }
 int engine_ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes) { return ensure_stage(e, in_bytes, out_bytes); }
 hipStream_t engine_stream(zgpu_engine *e) { return e->stream; }
 hipStream_t engine_copy_stream(zgpu_engine *e) { return e->copy_stream; }

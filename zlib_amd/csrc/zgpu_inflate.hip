@@ -28,6 +28,7 @@ void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 const uint8_t *engine_inflate_dict(zgpu_engine *e);
 uint32_t engine_inflate_dict_len(zgpu_engine *e);
+uint32_t engine_inflate_checks(zgpu_engine *e);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_scan(const ChunkMeta *meta, uint32_t nchunks, uint64_t chunk0, uint64_t *offsets, void *run, uint64_t out_cap, hipStream_t st, bool with_crc = false);
@@ -975,6 +976,8 @@ struct RunStateHostI { uint64_t out_total, in_total, ntokens; uint32_t adler_a, 
 // Adler-32 and CRC-32 of the produced bytes (same kernels as the compress side), over 64 KiB pieces of the output
 static int output_checksums(zgpu_engine *e, const uint8_t *d_out, uint64_t nbytes, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st)
 {
+    const uint32_t checks = engine_inflate_checks(e); // bit 0: Adler-32, bit 1: CRC-32 (zgpu_inflate_set_checks)
+    if (!checks) { engine_collect(e); res->adler32 = 1; res->crc32 = 0; return ZGPU_OK; }
     const uint64_t max_pieces = (out_cap >> 16) + 2;
     const uint32_t cbatch_cap = (uint32_t)(max_pieces < 65536 ? max_pieces : 65536);
     const uint64_t npieces = nbytes ? (nbytes + kChunkMax - 1) / kChunkMax : 1;
@@ -988,15 +991,15 @@ static int output_checksums(zgpu_engine *e, const uint8_t *d_out, uint64_t nbyte
         const uint32_t nb = (uint32_t)(npieces - c0 < cbatch ? npieces - c0 : cbatch);
         ChunkGeom g{}; g.in = d_out; g.in_bytes = nbytes; g.chunk_size = kChunkMax; g.chunk0 = c0; g.nchunks = nb; g.final_chunk = ~0ull;
         ZGPU_HIP_CHECK(hipMemsetAsync(meta, 0, (size_t)nb * sizeof(ChunkMeta), st));
-        launch_adler(g, meta, st);
-        launch_crc(g, meta, st);
-        launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st, true);
+        if (checks & 1u) launch_adler(g, meta, st); // (not computed: the pieces read a = 0, b = 0; the result is not reported)
+        if (checks & 2u) launch_crc(g, meta, st);
+        launch_scan(meta, nb, c0, oscr, engine_run_state(e), ~0ull, st, (checks & 2u) != 0);
     }
     ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, engine_run_state(e), sizeof rs, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     engine_collect(e);
-    res->adler32 = rs.adler_a | (rs.adler_b << 16);
-    res->crc32 = rs.crc;
+    res->adler32 = (checks & 1u) ? rs.adler_a | (rs.adler_b << 16) : 1u;
+    res->crc32 = (checks & 2u) ? rs.crc : 0u;
     return ZGPU_OK;
 }
 

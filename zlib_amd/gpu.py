@@ -8,6 +8,7 @@ _lib = None
 F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL, F_GZIP_WRAP, F_CRC32 = 1, 2, 4, 8, 16, 32
 WHOLE_STREAM = 0xFFFFFFFF  # inflate chunk_size: the one segment is a complete stream of any size
 LZ_AUTO, LZ_SERIAL, LZ_PARALLEL, LZ_SORTED, LZ_WALK, LZ_FAST = 0, 1, 2, 3, 4, 5
+CHECK_ADLER32, CHECK_CRC32 = 1, 2  # zgpu_inflate_set_checks
 STAGES = ["chain", "match", "parse", "lz_serial", "huffman", "stitch", "inflate"]
 CHUNK = 65536
 
@@ -81,6 +82,7 @@ def load_library():
     L.zgpu_crc32_device.argtypes = [vp, vp, u64, C.POINTER(u32), vp]
     L.zgpu_deflate_dict_chunk_host.argtypes = [vp, vp, u32, u32, vp, vp, u64, vp]
     L.zgpu_inflate_set_dictionary.argtypes = [vp, vp, u32]
+    L.zgpu_inflate_set_checks.argtypes = [vp, u32]
     L.zgpu_profile_enable.argtypes = [vp, C.c_int]
     L.zgpu_profile_enable.restype = None
     L.zgpu_profile_reset.argtypes = [vp]
@@ -122,6 +124,10 @@ class Engine:
     def inflate_set_dictionary(self, dictionary):
         d = bytes(dictionary) if dictionary else b""
         self._check(self.L.zgpu_inflate_set_dictionary(self.h, d if d else None, len(d)))
+
+    def inflate_set_checks(self, mask):
+        """Which checks of the decoded bytes the inflate calls that follow compute: CHECK_ADLER32 | CHECK_CRC32 (default both)."""
+        self._check(self.L.zgpu_inflate_set_checks(self.h, mask))
 
     def deflate_dict_chunk_host(self, dictionary, chunk, level, final, strategy=0, flags=0):
         """One chunk behind a preset dictionary (its last 32506 bytes count); returns the raw deflate stream of `chunk`."""

@@ -824,8 +824,10 @@ static int decode_some(z_streamp strm, size_t out_hint)
         const int first = s->produced == 0 && s->have_dict; /* the dictionary is what the window holds in front of the first byte only */
         e = engine_checkout();
         int rc = zgpu_inflate_set_dictionary(e, first ? s->dict.p : NULL, first ? (uint32_t)s->dict.len : 0u);
+        zgpu_inflate_set_checks(e, s->gz ? ZGPU_CHECK_CRC32 : ZGPU_CHECK_ADLER32); /* (the one check this stream's trailer holds: each is a pass over the output) */
         if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host2(e, src, srcn, ZGPU_INF_STREAM, s->out.p + s->out.len, cap, &r);
         if (first) zgpu_inflate_set_dictionary(e, NULL, 0);
+        zgpu_inflate_set_checks(e, ZGPU_CHECK_ADLER32 | ZGPU_CHECK_CRC32);
         engine_checkin(e);
         if (rc == ZGPU_BUF_ERROR) { cap = r.out_bytes > cap ? (size_t)r.out_bytes : cap * 4; if (cap > ((size_t)1 << 40)) { free(shifted); return Z_MEM_ERROR; } continue; }
         free(shifted);
