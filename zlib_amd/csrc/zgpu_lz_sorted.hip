@@ -234,7 +234,10 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
 #else
 #define S3_STOP(N) do { } while (0)
 #endif
-constexpr uint32_t kS3Threads = 1024, kS3Waves = kS3Threads / 64, kS3TurnSteps = 8, kS3TurnPos = 64 * kS3TurnSteps, kS3Batch = 8;
+#ifndef ZGPU_S3_BATCH
+#define ZGPU_S3_BATCH 8 // positions a lane has in flight in the index and scatter passes (A/B builds: scripts/build_variant.sh NAME -DZGPU_S3_BATCH=n)
+#endif
+constexpr uint32_t kS3Threads = 1024, kS3Waves = kS3Threads / 64, kS3TurnSteps = 8, kS3TurnPos = 64 * kS3TurnSteps, kS3Batch = ZGPU_S3_BATCH;
 struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 __device__ inline uint32_t lds_add_rtn32_nowait(uint32_t a, uint32_t v) { uint32_t o; asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(v) : "memory"); return o; }
 
