@@ -504,7 +504,10 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_huf_time(unsig
 #define HUF_TEND() do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(kThreads, 8) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
+#ifndef ZGPU_HUF_WAVES
+#define ZGPU_HUF_WAVES 8 // waves per SIMD the register budget is cut for (A/B builds: -DZGPU_HUF_WAVES=n; 6 and 7 spill less and keep fewer chunks resident)
+#endif
+__global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
 {
     __shared__ __attribute__((aligned(16))) TreeWork work0;
     __shared__ TreeWorkD work1;
