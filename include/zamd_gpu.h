@@ -54,6 +54,7 @@ extern "C" {
 #define ZGPU_LZ_SORTED 3   /* the same search over counting-sorted hash buckets: levels 4..9 */
 #define ZGPU_LZ_WALK 4     /* parse-driven search over the same buckets (only the positions deflate_slow searches): levels 4..9, the default */
 #define ZGPU_LZ_FAST 5     /* levels 1-3: deflate_fast over the sorted buckets, one lane per chunk, a flag byte per position for "in the chains" */
+#define ZGPU_LZ_FASTWIN 6  /* levels 1-3: deflate_fast, one wave per chunk, 64 positions a step, window + chain bits in LDS: the default there */
 
 typedef struct zgpu_engine zgpu_engine;
 

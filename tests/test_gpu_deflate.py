@@ -24,7 +24,7 @@ def eng():
 
 def impls(level):
     from zlib_amd import gpu
-    return [gpu.LZ_SERIAL] + ([gpu.LZ_PARALLEL, gpu.LZ_SORTED, gpu.LZ_WALK] if level >= 4 and PARALLEL else [gpu.LZ_FAST] if PARALLEL else [])
+    return [gpu.LZ_SERIAL] + ([gpu.LZ_PARALLEL, gpu.LZ_SORTED, gpu.LZ_WALK] if level >= 4 and PARALLEL else [gpu.LZ_FAST, gpu.LZ_FASTWIN] if PARALLEL else [])
 
 
 PARALLEL = True

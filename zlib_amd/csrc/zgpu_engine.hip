@@ -27,6 +27,7 @@ size_t lz_parallel_workspace_bytes(uint32_t batch_chunks);
 void launch_lz_parallel(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
 bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
+bool lz_fastwin_serves(const LevelCfg &cfg);
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
@@ -206,11 +207,15 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         // levels 1-3: the head[]/prev[] loop.  deflate_fast on the sorted buckets (ZGPU_LZ_FAST, fast_kernel in zgpu_lz_sorted.hip) is a second
         // implementation for the parity tests and for ZGPU_LZ_DEFAULT=5: it asks memory four times less often and is no faster
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env == ZGPU_LZ_FAST) impl = ZGPU_LZ_FAST;
+        // the default of levels 1-3: a wave per chunk, window and chain bits in LDS (zgpu_lz_fastwin.hip); ZGPU_LZ_DEFAULT=1 keeps the lane-per-chunk loop
+        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) impl = ZGPU_LZ_FASTWIN;
     }
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
     if (impl == ZGPU_LZ_FAST && (cfg.slow || !walk_ok || skip0 || !lz_parallel_available())) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_FAST serves levels 1..3, not Z_HUFFMAN_ONLY / Z_RLE, no dictionary chunk");
-    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_FAST) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
+    if (impl == ZGPU_LZ_FASTWIN && (cfg.slow || !walk_ok || skip0 || !lz_parallel_available() || !lz_fastwin_serves(cfg)))
+        return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_FASTWIN serves levels 1..3 with their own parameters, not Z_HUFFMAN_ONLY / Z_RLE, no dictionary chunk");
+    if (impl < ZGPU_LZ_SERIAL || impl > ZGPU_LZ_FASTWIN) return fail(e, ZGPU_STREAM_ERROR, "unknown lz_impl");
     if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
     if (impl == ZGPU_LZ_WALK && !walk_ok) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_WALK does not serve Z_HUFFMAN_ONLY / Z_RLE");
     if (skip0) { // a preset dictionary in front of the one chunk: the lane-per-chunk loop is the implementation that starts mid-window
@@ -256,7 +261,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST) && !e->exact_sort;
+    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN) && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, p->strategy, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
@@ -323,8 +328,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
             ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
             launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
         } else {
-            if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST)
-                adler_done = launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : 0);
+            if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN)
+                adler_done = launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : impl == ZGPU_LZ_FASTWIN ? 3 : 0);
             else launch_lz_parallel(g, cfg, e->par_ws, e->tokens, e->meta, st, e);
         }
         {

@@ -1,0 +1,361 @@
+// zgpu_lz_fastwin.hip -- LZ77 stage for levels 1-3: deflate_fast (/root/reference/qcsrc/deflate.c:1448-1546, longest_match :1027-1168),
+// one WAVE per chunk, 64 positions per step, the chunk's window and its hash chains in LDS.
+//
+// The chains of deflate_fast depend on the parse: the strings inside a match longer than max_insert_length never enter them
+// (deflate.c:1510-1534).  So neither head[]/prev[] filled ahead of the parse nor the static chains of levels 4-9 apply.  What IS known ahead of
+// the parse is which positions share a hash: sort3_kernel has counting-sorted the positions by hash (S; idx(p), rank(p) in `ir`), the bucket
+// predecessors of p, nearest first, are S[idx-1], S[idx-2], ... S[idx-rank], and the chain of p is those of them that have been inserted.
+// "Inserted" is ONE BIT PER S INDEX, kept in LDS (8 KiB): the bits of p's 32 nearest predecessors are 32 consecutive bits -- one read, and
+// the first `max_chain_length` set ones are the chain.  The bytes the candidates are compared with come from a ring of the last 33 KiB of the
+// chunk in LDS (MAX_DIST + lookahead); the S entries and ir words of a window are fetched from HBM one and two windows ahead of the parse (they
+// do not depend on it), so no trip to memory lies on the chain of dependent steps.  47 KiB of LDS per chunk: three chunks per CU.
+//
+// A window: every lane evaluates longest_match at its own position under the bits as they stand -- final below the window, a guess ("set")
+// inside it; a scalar walk follows the token starts (a literal run is one step); a match longer than max_insert_length clears the bits of its
+// inside; then every lane reads its bits again: a token start whose search had examined a bit that is now clear is stale, the tokens in front of
+// the first stale one stand, everything from there on is evaluated again (1.5 evaluations per window on the Silesia-mix,
+// tests/tools/fastwin_model.c, which is this algorithm on the CPU, checked against the plain loop).  A search that needs more than 32
+// predecessors (1.5 % at level 1) is done over the whole bucket by all lanes when the walk stands on it.
+#include "zgpu_common.h"
+#include <cstdlib>
+
+namespace zgpu {
+
+constexpr uint32_t kSPadF = 8, kSStrideF = kChunkMax + kSPadF; // S layout of zgpu_lz_sorted.hip (kSPad entries in front of every chunk's S)
+constexpr uint32_t kFwRing = 34 * 1024;             // bytes of the chunk in LDS: MAX_DIST back, a window + MAX_MATCH ahead, filled 1 KiB at a time
+constexpr uint32_t kFwMirror = 48;                  // the ring's first bytes again behind its end: a 40-byte read (nice_match 32 + 8) may start at its last byte
+constexpr uint32_t kFwFlagWords = kChunkMax / 32 + 2;
+constexpr uint32_t kFwStgStride = 80;               // bytes per lane of the staged S entries (64 + 16: 16-byte stores free of bank conflicts)
+constexpr uint32_t kFwOffFlags = kFwRing + kFwMirror;
+constexpr uint32_t kFwOffStg = (kFwOffFlags + kFwFlagWords * 4 + 15) & ~15u;
+constexpr uint32_t kFwLds = kFwOffStg + 64 * kFwStgStride;
+constexpr uint32_t kFwDepth = 32;                   // predecessors a lane looks at
+constexpr uint32_t kResLen = 511, kResTerm = 1u << 9, kResInc = 1u << 10;
+
+struct __attribute__((packed, aligned(1))) FwU128 { uint4 v; };
+struct __attribute__((packed, aligned(1))) FwU32 { uint32_t v; };
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ inline uint32_t fw_lds_base(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
+// 8 / 4 bytes at any LDS byte offset (the hardware serves unaligned ds reads; their 36 clocks in the LDS cost one issue slot)
+__device__ inline uint64_t fw_ld64(uint32_t a) { uint64_t v; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory"); return v; }
+__device__ inline uint32_t fw_ld32(uint32_t a) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory"); return v; }
+__device__ inline void fw_ld64x2(uint32_t a, uint32_t b, uint64_t &x, uint64_t &y)
+{
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(a), "v"(b) : "memory");
+}
+__device__ inline void fw_ld64x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint64_t &x, uint64_t &y, uint64_t &z, uint64_t &w)
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w) : "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
+}
+__device__ inline uint32_t fw_ring(uint32_t p) { const uint32_t d = p - kFwRing; return p < d ? p : d; } // p mod ring size, p < 2 * ring
+__device__ inline uint32_t fw_diff8(uint64_t x) { return x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u; }
+
+__device__ __noinline__ uint4 fw_tail16(const uint8_t *in, uint32_t o, uint64_t safe_end)
+{
+    uint32_t v[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16 && (uint64_t)o + k < safe_end; k++) v[k >> 2] |= (uint32_t)in[o + k] << (8 * (k & 3));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// CHAIN: max_chain_length; NICE: nice_match (a multiple of 8: the lanes compare that many bytes of every candidate, a match that reaches it is
+// measured by all lanes together when the walk takes it)
+template <int CHAIN, int NICE>
+__global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_insert, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
+                                                      uint32_t *__restrict__ tokens, ChunkMeta *__restrict__ meta)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
+    static_assert(NICE % 8 == 0 && NICE >= 8 && NICE <= 32 && CHAIN % 4 == 0, "whole groups of four candidates, whole 8-byte steps");
+    constexpr int NW = NICE / 8;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    const uint64_t safe_end = g.in_bytes - lo;
+    const uint16_t *S = S_all + (size_t)c * kSStrideF + kSPadF;
+    const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
+    uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t base = chunk_base(g, c), npos = n >= 3 ? n - 2 : 0;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
+    const uint32_t ring_a = fw_lds_base(fw_lds), stg_a = fw_lds_base(fw_lds + kFwOffStg) + lane * kFwStgStride;
+    const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
+
+    for (uint32_t i = lane; i < kFwFlagWords; i += 64) flags[i] = 0;
+
+    // ---- the ring: block k (1 KiB of the chunk) lives at (k mod 34) KiB ----
+    uint32_t filled = 0;
+    auto fill_to = [&](uint32_t need) { // (uniform)
+        while (filled < need) {
+            const uint32_t o = filled + 16 * lane;
+            uint4 v;
+            if ((uint64_t)o + 16 <= safe_end) v = reinterpret_cast<const FwU128 *>(src + o)->v; else v = fw_tail16(src, o, safe_end);
+            const uint32_t ro = fw_ring(filled) + 16 * lane;
+            *reinterpret_cast<uint4 *>(fw_lds + ro) = v;
+            if (ro < kFwMirror) *reinterpret_cast<uint4 *>(fw_lds + kFwRing + ro) = v;
+            filled += 1024;
+        }
+    };
+    fill_to(1024);
+
+    // ---- block bookkeeping (cut_block of zgpu_lz_serial.hip; deflate.c:1365-1367 for `nostore`) ----
+    uint32_t off = 0, ntok = 0, blk_tok0 = 0, nblk = 0, nostore = 0, block_start = 0;
+    const uint32_t room = 2 * kWSize - base;
+    uint32_t buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
+    auto token_top = [&](uint32_t p) { // the loop top of deflate_fast for the token that starts at p: fill_window and its slide (deflate.c:1293)
+        if (buffered - p < kMinLookahead) { if ((int)(p + base) - (int)off >= (int)(kWSize + kMaxDist)) off += kWSize; buffered = n; }
+    };
+    auto cut_block = [&](uint32_t p_end) {
+        if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk;
+        nblk++; blk_tok0 += kBlockTokens; block_start = p_end;
+    };
+
+    // ---- what is fetched ahead: ir of the window after next, the S entries of the next window ----
+    auto load_ir = [&](uint32_t w) -> uint32_t { const uint32_t p = w * 64 + lane; return p < npos ? ir[p] : 0u; };
+    uint4 sq0, sq1, sq2, sq3; // S[idx-32 .. idx-1] of this lane's position: 64 bytes, the nearest predecessor last
+    auto load_s = [&](uint32_t iv) {
+        const uint32_t rk = iv >> 16;
+        const uint8_t *a = reinterpret_cast<const uint8_t *>(S) + 2 * (int)(iv & 0xffffu) - 64; // (below S[0]: the pad and the chunk in front, or the header -- masked by the rank)
+        sq0 = sq1 = sq2 = sq3 = make_uint4(0, 0, 0, 0);
+        if (rk > 0) sq3 = reinterpret_cast<const FwU128 *>(a + 48)->v;
+        if (rk > 8) sq2 = reinterpret_cast<const FwU128 *>(a + 32)->v;
+        if (rk > 16) sq1 = reinterpret_cast<const FwU128 *>(a + 16)->v;
+        if (rk > 24) sq0 = reinterpret_cast<const FwU128 *>(a)->v;
+    };
+    uint32_t ir_cur = load_ir(0), ir_nxt = load_ir(1);
+    load_s(ir_cur);
+
+    uint32_t pos = 0;        // where the next token starts
+    bool cross_short = false; // the match that reaches into this window was a short one: its strings are in the chains
+    const uint32_t nwin = (n + 63) / 64;
+    __syncthreads();
+
+    for (uint32_t win = 0; win < nwin; win++) {
+        const uint32_t w0 = win * 64, p = w0 + lane;
+        const bool skip = pos >= w0 + 64; // the window lies inside a match (a long one: a short one ends within six positions)
+        if (!skip) { // the staged entries of this window
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 16) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 32) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 48) = sq3;
+        }
+        const uint32_t iv = ir_cur;
+        load_s(ir_nxt);
+        ir_cur = ir_nxt;
+        ir_nxt = load_ir(win + 2);
+        fill_to(w0 + 64 + kMaxMatch + NICE + 16 < kChunkMax + 1024 ? w0 + 64 + kMaxMatch + NICE + 16 : kChunkMax + 1024);
+        if (skip) continue;
+
+        const uint32_t idx = iv & 0xffffu, rk = iv >> 16;
+        const bool haspos = p < npos;
+        const uint32_t B0 = 65536u - idx;                       // bit B0 + k of the (reversed) bitmap belongs to predecessor k
+        const uint32_t own_w = (B0 - 1) >> 5, own_b = 1u << ((B0 - 1) & 31u);
+        const uint32_t entry = pos - w0;
+        if (haspos && (lane >= entry || cross_short)) atomicOr(&flags[own_w], own_b);
+        const uint32_t look = n > p ? n - p : 0, cap = look < kMaxMatch ? look : kMaxMatch, ni = (uint32_t)NICE < look ? (uint32_t)NICE : look;
+        const uint32_t cmp_max = cap < (uint32_t)NICE ? cap : (uint32_t)NICE;
+        const int w = (int)(p + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+        uint64_t own[NW];
+        const uint32_t own_a = ring_a + fw_ring(p);
+        if (NW == 1) own[0] = fw_ld64(own_a);
+        else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        const uint32_t own_byte = (uint32_t)own[0] & 255u;
+
+        uint32_t res = 1, mstart = 0, mex = 0; // this lane's search: length | kResTerm | kResInc; where the match starts; the bits it examined
+        const uint32_t lend = n - w0 < 64 ? n - w0 : 64; // lanes of this window that are positions of the chunk
+        auto read_bits = [&]() -> uint32_t {
+            const uint32_t wa = B0 >> 5, lo32 = flags[wa], hi32 = flags[wa + 1];
+            uint32_t m = __builtin_amdgcn_alignbit(hi32, lo32, B0 & 31u);
+            if (rk < 32) m &= (1u << rk) - 1u;
+            return m;
+        };
+
+        uint32_t start = entry;
+        bool need_eval = true, dirty = false; // dirty: bits have been cleared since the lanes from `start` on were evaluated
+        for (;;) { // rounds
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (need_eval) dirty = false;
+            if (need_eval && lane >= start) {
+                res = 1; mstart = 0; mex = 0;
+                if (haspos && rk != 0) {
+                    uint32_t m = read_bits(), best = kMinMatch - 1, nsel = 0;
+                    bool first = true, stopped = false, term = false;
+#pragma unroll 1
+                    for (int g0 = 0; g0 < CHAIN; g0 += 4) {
+                        if (__builtin_amdgcn_ballot_w64(!stopped && m != 0) == 0) break;
+                        uint32_t k[4], q[4]; bool v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + kFwOffStg + lane * kFwStgStride + 62 - 2 * k[u]);
+                        uint64_t cb[4][NW];
+                        {
+                            const uint32_t a0 = ring_a + fw_ring(q[0]), a1 = ring_a + fw_ring(q[1]), a2 = ring_a + fw_ring(q[2]), a3 = ring_a + fw_ring(q[3]);
+#pragma unroll
+                            for (int t = 0; t < NW; t++) fw_ld64x4(a0 + 8 * t, a1 + 8 * t, a2 + 8 * t, a3 + 8 * t, cb[0][t], cb[1][t], cb[2][t], cb[3][t]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (v[u] && !stopped) { // longest_match's bookkeeping for this candidate (deflate.c:1126-1163)
+                                mex |= 1u << k[u];
+                                const int wq = (int)(q[u] + base);
+                                const bool far = first ? (wq <= 0 || (uint32_t)(w - wq) > kMaxDist) : wq <= limit; // hash_head out of reach: no search (deflate.c:1481); the chain ends (:1163)
+                                if (far) stopped = true;
+                                else {
+                                    first = false; nsel++;
+                                    uint32_t l = 0;
+#pragma unroll
+                                    for (int t = 0; t < NW; t++) if (l == 8u * t) l += fw_diff8(cb[u][t] ^ own[t]);
+                                    l = l < cmp_max ? l : cmp_max;
+                                    if (l > best) { best = l; mstart = q[u]; if (l >= ni) { stopped = true; term = l < cap; } }
+                                    if (nsel == (uint32_t)CHAIN) stopped = true;
+                                }
+                            }
+                        }
+                    }
+                    if (!first && best >= kMinMatch) res = best | (term ? kResTerm : 0u);
+                    if (!stopped && nsel < (uint32_t)CHAIN && rk > kFwDepth) res = kResInc; // the chain may go on below the bits this lane has
+                }
+            }
+            // ---- the walk over the token starts, from `start` ----
+            const uint64_t nonlit = __builtin_amdgcn_ballot_w64(res != 1u);
+            uint64_t T = 0, C = 0;
+            uint32_t L = start, stop_inc = 64;
+            bool cs_new = cross_short;
+            while (L < lend) {
+                const uint64_t ahead = nonlit >> L;
+                const uint32_t run = ahead ? (uint32_t)__builtin_ctzll(ahead) : 64u; // literals up to the next lane with a match
+                const uint32_t Lm = L + run < lend ? L + run : lend;
+                if (Lm > L) T |= (Lm - L >= 64 ? ~0ull : ((1ull << (Lm - L)) - 1ull)) << L;
+                L = Lm;
+                if (L >= lend) break;
+                uint32_t x = __builtin_amdgcn_readlane(res, L);
+                if (x & kResInc) { stop_inc = L; break; }
+                T |= 1ull << L;
+                uint32_t len = x & kResLen;
+                const uint32_t p0 = w0 + L;
+                if (x & kResTerm) { // all lanes measure the match: four bytes each behind the NICE the lane has compared
+                    const uint32_t q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
+                    const uint32_t o = NICE + 4 * lane;
+                    const uint32_t xa = fw_ld32(ring_a + fw_ring(q0 + o)) ^ fw_ld32(ring_a + fw_ring(p0 + o));
+                    const uint64_t ne = __builtin_amdgcn_ballot_w64(xa != 0);
+                    if (ne == 0) len = cap0;
+                    else {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(ne), xf = __builtin_amdgcn_readlane(xa, f);
+                        len = NICE + 4 * f + ((uint32_t)__builtin_ctz(xf) >> 3);
+                        len = len < cap0 ? len : cap0;
+                    }
+                    res = lane == L ? len : res; // (the length is known now, whatever becomes of this round)
+                }
+                const bool sh = len <= max_insert && n - p0 - len >= kMinMatch;
+                if (!sh) { // the strings inside this match stay out of the chains
+                    const uint32_t e = L + len < 64 ? L + len : 64;
+                    if (e > L + 1) C |= ((1ull << (e - L - 1)) - 1ull) << (L + 1);
+                }
+                if (L + len >= 64) cs_new = sh;
+                L += len;
+            }
+            // ---- which of these tokens stand ----
+            if ((C & lane_bit) && haspos) atomicAnd(&flags[own_w], ~own_b);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            dirty = dirty || C != 0;
+            bool stale = false;
+            if (dirty && lane >= start && mex != 0) stale = (mex & ~read_bits()) != 0;
+            const uint64_t st_mask = __builtin_amdgcn_ballot_w64(stale) & T;
+            const uint32_t Lstale = st_mask ? (uint32_t)__builtin_ctzll(st_mask) : 64u;
+            const uint32_t Lacc = Lstale < stop_inc ? Lstale : stop_inc; // the tokens that start below Lacc are the reference's
+            const uint64_t Tacc = Lacc >= 64 ? T : T & ((1ull << Lacc) - 1ull);
+            const uint32_t end_pos = Lacc >= 64 ? w0 + L : w0 + Lacc; // where the token behind the accepted ones starts
+            // the accepted tokens
+            {
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(Tacc);
+                if (Tacc & lane_bit) {
+                    const uint32_t ln = res & kResLen;
+                    tok[ntok + (uint32_t)__builtin_popcountll(Tacc & lanes_below)] = ln == 1 ? tok_lit(own_byte) : tok_match(p - mstart, ln - kMinMatch);
+                }
+                const bool near_end = w0 + 64 + kMinLookahead > (buffered < n ? buffered : n);
+                if (near_end || ntok + cnt - blk_tok0 >= kBlockTokens) { // the rare windows in which the slide or a block cut happens: token by token
+                    uint64_t t = Tacc; uint32_t k = 0;
+                    while (t) {
+                        const uint32_t l0 = (uint32_t)__builtin_ctzll(t); t &= t - 1;
+                        token_top(w0 + l0);
+                        k++;
+                        if (ntok + k - blk_tok0 == kBlockTokens) cut_block(t ? w0 + (uint32_t)__builtin_ctzll(t) : end_pos);
+                    }
+                }
+                ntok += cnt;
+            }
+            if (Lacc >= 64 || Lacc >= lend) { pos = w0 + L; cross_short = cs_new; break; }
+            // the bits behind the accepted tokens are guesses again
+            if (lane >= Lacc && (C & lane_bit) && haspos) atomicOr(&flags[own_w], own_b);
+            start = Lacc;
+            if (Lstale <= stop_inc) { need_eval = true; continue; }
+            // ---- the search at Lacc over its whole bucket, by all lanes (every bit below it is final now) ----
+            {
+                const uint32_t p0 = w0 + Lacc, i0 = __builtin_amdgcn_readlane(idx, Lacc), r0 = __builtin_amdgcn_readlane(rk, Lacc);
+                const uint32_t look0 = n - p0, cap0 = look0 < kMaxMatch ? look0 : kMaxMatch, ni0 = (uint32_t)NICE < look0 ? (uint32_t)NICE : look0;
+                const int w00 = (int)(p0 + base), limit0 = w00 > (int)kMaxDist ? w00 - (int)kMaxDist : 0;
+                uint32_t best = kMinMatch - 1, ms0 = 0, ch = CHAIN;
+                bool first = true, done = false;
+                const uint32_t pa = ring_a;
+                for (uint32_t k0 = 0; k0 < r0 && !done; k0 += 64) {
+                    const uint32_t kk = k0 + lane;
+                    const bool valid = kk < r0;
+                    const uint32_t q = valid ? S[(int)i0 - 1 - (int)kk] : 0u;
+                    const uint32_t rv = 65536u - i0 + kk;
+                    const bool ins = valid && ((flags[rv >> 5] >> (rv & 31u)) & 1u);
+                    uint32_t l = 0;
+                    if (ins && (int)(q + base) > limit0 - 1) { // (a candidate out of reach is turned away before its length is asked for; its bytes may have left the ring)
+                        for (;;) {
+                            const uint32_t d = fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l)));
+                            l += d;
+                            if (d < 8 || l >= cap0) break;
+                        }
+                        l = l < cap0 ? l : cap0;
+                    }
+                    uint64_t im = __builtin_amdgcn_ballot_w64(ins);
+                    while (im) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(im); im &= im - 1;
+                        const uint32_t qf = __builtin_amdgcn_readlane(q, f), lf = __builtin_amdgcn_readlane(l, f);
+                        const int wq = (int)(qf + base);
+                        if (first ? (wq <= 0 || (uint32_t)(w00 - wq) > kMaxDist) : wq <= limit0) { done = true; break; }
+                        first = false;
+                        if (lf > best) { best = lf; ms0 = qf; if (lf >= ni0) { done = true; break; } }
+                        if (--ch == 0) { done = true; break; }
+                    }
+                }
+                const uint32_t r1 = (!first && best >= kMinMatch) ? best : 1u;
+                if (lane == Lacc) { res = r1; mstart = ms0; mex = 0; }
+            }
+            need_eval = false;
+        }
+    }
+    token_top(n); // the loop top that finds the input at its end (deflate.c:1459-1466): the slide may still happen here
+    if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // the final block (its emission happens in the Huffman stage)
+    if (lane == 0) { meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n; }
+}
+
+// the levels' own parameters only (deflate.c:137-149): a tuned stream goes to the lane-per-chunk loop
+bool lz_fastwin_serves(const LevelCfg &cfg)
+{
+    if (cfg.slow || cfg.good != 4) return false;
+    return (cfg.chain == 4 && cfg.nice == 8) || (cfg.chain == 8 && cfg.nice == 16) || (cfg.chain == 32 && cfg.nice == 32);
+}
+
+void launch_lz_fastwin(const ChunkGeom &g, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    static bool opt_in = false;
+    if (!opt_in) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        opt_in = true;
+    }
+    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_kernel<4, 8>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_kernel<8, 16>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+    else hipLaunchKernelGGL((fastwin_kernel<32, 32>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+}
+
+} // namespace zgpu

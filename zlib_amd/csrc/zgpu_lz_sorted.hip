@@ -34,6 +34,7 @@ void prof_span_begin(void *eng, hipStream_t st, hipEvent_t *a);
 void prof_span_end(void *eng, hipStream_t st, int stage, hipEvent_t a);
 void launch_parse(const ChunkGeom &g, LevelCfg cfg, const uint2 *recs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
 void launch_parse_lite(const ChunkGeom &g, LevelCfg cfg, const uint32_t *gm, const uint32_t *gs, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_lz_fastwin(const ChunkGeom &g, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
 
 __device__ inline uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 // wave-private LDS words by byte offset (plain C++ volatile accesses through a generic pointer compile to flat_* memory instructions)
@@ -1218,7 +1219,7 @@ __global__ void __launch_bounds__(64) fast_kernel(ChunkGeom g, LevelCfg cfg, con
 
 // `exact_sort`: use the ballot-only sort (the engine sets it after sort3's pass V reported a fault, or ZGPU_SORT=1 asks)
 // `walk`: parse-driven search (walk_kernel + the lite parse) instead of the all-position search (match3_kernel + parse2_kernel)
-// `walk` 2: levels 1-3, deflate_fast on the sorted buckets (fast_kernel)
+// `walk` 2: levels 1-3, deflate_fast on the sorted buckets (fast_kernel); `walk` 3: the same by a wave per chunk (zgpu_lz_fastwin.hip)
 // returns true when the sort has left the chunks' Adler-32 in meta[] (sort3_kernel does; the ballot-only sort does not)
 bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk)
 {
@@ -1246,6 +1247,11 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
     prof_span_begin(prof, st, &ev);
+    if (walk == 3) {
+        launch_lz_fastwin(g, cfg, S, ir, tokens, meta, st);
+        prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+        return adler_done;
+    }
     if (walk == 2) { // the records' memory holds the flag bytes
         uint8_t *G = reinterpret_cast<uint8_t *>(recs);
         hipMemsetAsync(G, 0, nch * kGStride, st);

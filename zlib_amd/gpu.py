@@ -7,7 +7,7 @@ _lib = None
 
 F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL, F_GZIP_WRAP, F_CRC32 = 1, 2, 4, 8, 16, 32
 WHOLE_STREAM = 0xFFFFFFFF  # inflate chunk_size: the one segment is a complete stream of any size
-LZ_AUTO, LZ_SERIAL, LZ_PARALLEL, LZ_SORTED, LZ_WALK, LZ_FAST = 0, 1, 2, 3, 4, 5
+LZ_AUTO, LZ_SERIAL, LZ_PARALLEL, LZ_SORTED, LZ_WALK, LZ_FAST, LZ_FASTWIN = 0, 1, 2, 3, 4, 5, 6
 CHECK_ADLER32, CHECK_CRC32 = 1, 2  # zgpu_inflate_set_checks
 STAGES = ["chain", "match", "parse", "lz_serial", "huffman", "stitch", "inflate"]
 CHUNK = 65536
