@@ -19,6 +19,24 @@
 #include "zgpu_common.h"
 #include <cstdlib>
 
+#ifdef ZGPU_FW_TIME // timing builds only (scripts/build_variant.sh fwtime -DZGPU_FW_TIME; scripts/fw_time.py): cycles by phase, counts
+__device__ unsigned long long g_fw_time[16];
+extern "C" __attribute__((visibility("default"))) void zgpu_debug_fw_time(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = {0};
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fw_time), z, sizeof z); else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fw_time), sizeof z);
+}
+#define FW_T0() unsigned long long fw_t_ = __builtin_amdgcn_s_memtime(); unsigned long long fw_acc_[16] = {0}
+#define FW_LAP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); fw_acc_[k] += n_ - fw_t_; fw_t_ = n_; } while (0)
+#define FW_CNT(k, v) do { fw_acc_[k] += (v); } while (0)
+#define FW_END() do { if (lane == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_fw_time[k_], fw_acc_[k_]); } while (0)
+#else
+#define FW_T0() do { } while (0)
+#define FW_LAP(k) do { } while (0)
+#define FW_CNT(k, v) do { } while (0)
+#define FW_END() do { } while (0)
+#endif
+
 namespace zgpu {
 
 constexpr uint32_t kSPadF = 8, kSStrideF = kChunkMax + kSPadF; // S layout of zgpu_lz_sorted.hip (kSPad entries in front of every chunk's S)
@@ -82,6 +100,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
 
     for (uint32_t i = lane; i < kFwFlagWords; i += 64) flags[i] = 0;
+    FW_T0();
 
     // ---- the ring: block k (1 KiB of the chunk) lives at (k mod 34) KiB ----
     uint32_t filled = 0;
@@ -144,7 +163,9 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
         ir_cur = ir_nxt;
         ir_nxt = load_ir(win + 2);
         fill_to(w0 + 64 + kMaxMatch + NICE + 16 < kChunkMax + 1024 ? w0 + 64 + kMaxMatch + NICE + 16 : kChunkMax + 1024);
+        FW_LAP(0);
         if (skip) continue;
+        FW_CNT(8, 1);
 
         const uint32_t idx = iv & 0xffffu, rk = iv >> 16;
         const bool haspos = p < npos;
@@ -176,6 +197,9 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (need_eval) dirty = false;
+            FW_LAP(1);
+            FW_CNT(9, 1);
+            if (need_eval) FW_CNT(10, 1);
             if (need_eval && lane >= start) {
                 res = 1; mstart = 0; mex = 0;
                 if (haspos && rk != 0) {
@@ -218,6 +242,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                     if (!stopped && nsel < (uint32_t)CHAIN && rk > kFwDepth) res = kResInc; // the chain may go on below the bits this lane has
                 }
             }
+            FW_LAP(2);
             // ---- the walk over the token starts, from `start` ----
             const uint64_t nonlit = __builtin_amdgcn_ballot_w64(res != 1u);
             uint64_t T = 0, C = 0;
@@ -235,6 +260,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                 T |= 1ull << L;
                 uint32_t len = x & kResLen;
                 const uint32_t p0 = w0 + L;
+                if (x & kResTerm) FW_CNT(11, 1);
                 if (x & kResTerm) { // all lanes measure the match: four bytes each behind the NICE the lane has compared
                     const uint32_t q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
                     const uint32_t o = NICE + 4 * lane;
@@ -256,6 +282,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                 if (L + len >= 64) cs_new = sh;
                 L += len;
             }
+            FW_LAP(3);
             // ---- which of these tokens stand ----
             if ((C & lane_bit) && haspos) atomicAnd(&flags[own_w], ~own_b);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -268,6 +295,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
             const uint32_t Lacc = Lstale < stop_inc ? Lstale : stop_inc; // the tokens that start below Lacc are the reference's
             const uint64_t Tacc = Lacc >= 64 ? T : T & ((1ull << Lacc) - 1ull);
             const uint32_t end_pos = Lacc >= 64 ? w0 + L : w0 + Lacc; // where the token behind the accepted ones starts
+            FW_LAP(4);
             // the accepted tokens
             {
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(Tacc);
@@ -287,11 +315,13 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                 }
                 ntok += cnt;
             }
+            FW_LAP(5);
             if (Lacc >= 64 || Lacc >= lend) { pos = w0 + L; cross_short = cs_new; break; }
             // the bits behind the accepted tokens are guesses again
             if (lane >= Lacc && (C & lane_bit) && haspos) atomicOr(&flags[own_w], own_b);
             start = Lacc;
             if (Lstale <= stop_inc) { need_eval = true; continue; }
+            FW_CNT(12, 1);
             // ---- the search at Lacc over its whole bucket, by all lanes (every bit below it is final now) ----
             {
                 const uint32_t p0 = w0 + Lacc, i0 = __builtin_amdgcn_readlane(idx, Lacc), r0 = __builtin_amdgcn_readlane(rk, Lacc);
@@ -330,8 +360,10 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                 if (lane == Lacc) { res = r1; mstart = ms0; mex = 0; }
             }
             need_eval = false;
+            FW_LAP(6);
         }
     }
+    FW_END();
     token_top(n); // the loop top that finds the input at its end (deflate.c:1459-1466): the slide may still happen here
     if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // the final block (its emission happens in the Huffman stage)
     if (lane == 0) { meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n; }
