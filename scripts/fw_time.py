@@ -24,14 +24,11 @@ f(out, 1)
 e.deflate_device(src.data_ptr(), n * 65536, lvl, dst.data_ptr(), cap, flags=gpu.F_FINAL)
 torch.cuda.synchronize()
 f(out, 0)
-names = {0: "window top: staging, loads, ring", 1: "round top", 2: "evaluation", 3: "walk + own bits", 4: "stale check", 5: "tokens", 6: "whole-bucket search",
-         7: "waiting for the turn", 15: "hand-off"}
-tot = sum(int(out[i]) for i in names)
+names = ["window top: staging, loads, ring", "round top", "evaluation", "walk", "clears + stale check", "tokens", "whole-bucket search"]
+tot = sum(int(out[i]) for i in range(7))
 win = int(out[8]) / n
-print("level %d kind %d, %d chunks: %.0f windows a chunk; per window: ahead of the parse %.2f rounds, %.2f evaluations; at the turn %.2f rounds, %.2f evaluations; "
-      "%.1f matches measured by all lanes and %.1f whole-bucket searches a chunk"
-      % (lvl, kind, n, win, int(out[13]) / max(1, int(out[8])), int(out[10]) / max(1, int(out[8])), int(out[9]) / max(1, int(out[8])), int(out[14]) / max(1, int(out[8])),
-         int(out[11]) / n, int(out[12]) / n))
-for i, nm in names.items():
+print("level %d kind %d, %d chunks: %.0f windows a chunk, %.2f rounds and %.2f evaluations a window, %.1f measured matches and %.1f whole-bucket searches a chunk"
+      % (lvl, kind, n, win, int(out[9]) / max(1, int(out[8])), int(out[10]) / max(1, int(out[8])), int(out[11]) / n, int(out[12]) / n))
+for i, nm in enumerate(names):
     print("%-34s %9.0f cycles per chunk  %6.0f per window  %5.1f%%" % (nm, int(out[i]) / n, int(out[i]) / n / win, 100.0 * int(out[i]) / tot))
-print("total %.0f wave-cycles per chunk (all waves), %.0f per window" % (tot / n, tot / n / win))
+print("total %.0f cycles per chunk, %.0f per window" % (tot / n, tot / n / win))

@@ -207,8 +207,14 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         // levels 1-3: the head[]/prev[] loop.  deflate_fast on the sorted buckets (ZGPU_LZ_FAST, fast_kernel in zgpu_lz_sorted.hip) is a second
         // implementation for the parity tests and for ZGPU_LZ_DEFAULT=5: it asks memory four times less often and is no faster
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env == ZGPU_LZ_FAST) impl = ZGPU_LZ_FAST;
-        // the default of levels 1-3: a wave per chunk, window and chain bits in LDS (zgpu_lz_fastwin.hip); ZGPU_LZ_DEFAULT=1 keeps the lane-per-chunk loop
-        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) impl = ZGPU_LZ_FASTWIN;
+        // levels 1-3: a wave per chunk, window and chain bits in LDS (zgpu_lz_fastwin.hip) -- 5 ms a chunk whatever the size of the call, three chunks per
+        // CU; the lane-per-chunk loop takes 28 ms a chunk and needs tens of thousands of them in flight.  Measured crossovers (chunks per call, 4 GiB =
+        // 65536): level 1 about 40000, level 2 about 28000, level 3 (32 candidates a lane) about 4000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
+        if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) {
+            const uint64_t cs0 = p->chunk_size ? p->chunk_size : kChunkMax, nch0 = d_seg ? nseg : (in_bytes + cs0 - 1) / cs0;
+            const uint64_t upto = cfg.chain == 4 ? 36864 : cfg.chain == 8 ? 24576 : 4096;
+            if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;
+        }
     }
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
         return fail(e, ZGPU_STREAM_ERROR, "parallel LZ77 serves levels 4..9 only");
