@@ -85,9 +85,10 @@ typedef struct {
     int32_t error_code;   /* ZGPU_OK or the failure of first_bad_chunk */
     uint32_t error_msg;   /* index into zgpu_inflate_message() */
     uint32_t crc32;       /* CRC-32 of the produced bytes */
-    uint32_t reserved;
-    /* zgpu_inflate_stream_host2 with ZGPU_INF_STREAM (otherwise in_used = in_bytes, the flags 0): */
-    uint64_t in_used;     /* input bytes consumed: up to the end of the final block, or of the last segment that decoded */
+    uint32_t in_used_bits; /* with `incomplete`: bits of the byte at in + in_used that are consumed as well (0..7): the stream goes on at that bit
+                              (zgpu_inflate_stream_host3's start_bit) */
+    /* zgpu_inflate_stream_host2 / 3 with ZGPU_INF_STREAM (otherwise in_used = in_bytes, the flags 0): */
+    uint64_t in_used;     /* input bytes consumed: up to the end of the final block, or of the last segment / piece that decoded */
     uint32_t stream_end;  /* the final block was reached */
     uint32_t incomplete;  /* the input stops inside a block: out_bytes / in_used cover the segments in front of it (possibly none) */
 } zgpu_inflate_result;
@@ -173,6 +174,13 @@ int zgpu_inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, 
  * the input with the caller).  flags = 0 is zgpu_inflate_stream_host. */
 #define ZGPU_INF_STREAM 1u
 int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap,
+                              zgpu_inflate_result *res);
+/* The same for a stream that is taken up again INSIDE a byte: a stream of another producer that carries no flush markers is delivered piece by
+ * piece as it arrives (qcsrc/inflate.c:323-371: the reference's inflate() hands output on with 32 KiB of window kept; here the caller keeps the
+ * last 32 KiB it received and gives them to zgpu_inflate_set_dictionary before the next call).  A call whose input stops inside a block returns
+ * the whole pieces in front of it (res->incomplete, res->out_bytes) and where they end: byte res->in_used, bit res->in_used_bits -- the next call
+ * passes in + in_used and start_bit = in_used_bits.  start_bit 0 is zgpu_inflate_stream_host2. */
+int zgpu_inflate_stream_host3(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t start_bit, uint32_t flags, void *out, uint64_t out_cap,
                               zgpu_inflate_result *res);
 /* A body that does not split at flush markers and holds at least 128 KiB (ZGPU_SPEC_MIN_BYTES) is decoded in pieces all the same: block starts
  * are searched behind every 1/4096 of the input (at least 32 KiB apart), every piece is decoded with the 32 KiB in front of it unknown,

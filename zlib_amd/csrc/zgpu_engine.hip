@@ -31,7 +31,7 @@ bool lz_fastwin_serves(const LevelCfg &cfg);
 uint32_t *lz_sorted_fault_word(void *workspace);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
-                const uint64_t *h_offsets = nullptr, bool open_end = false, uint8_t *h_dst = nullptr);
+                const uint64_t *h_offsets = nullptr, bool open_end = false, uint8_t *h_dst = nullptr, uint64_t h_cap = 0);
 
 } // namespace zgpu
 
@@ -586,9 +586,10 @@ int zgpu_inflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const u
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->offsets, chunk_offsets, (nchunks + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     // direct placement with room for every chunk: the output goes to the caller's buffer batch by batch, under the decoding of the next batch
-    const bool stream_out = chunk_size != 0 && chunk_size <= kChunkMax; // (copies stop at out_cap: a buffer that is too small is reported as before)
+    // (the device buffer has room for nchunks whole chunks; the caller's buffer has out_cap bytes, and no copy into it goes beyond them)
+    const bool stream_out = chunk_size != 0 && chunk_size <= kChunkMax;
     rc = inflate_run(e, e->stage_in, in_bytes, e->offsets, nchunks, chunk_size, e->stage_out, need_out, res, e->stream, 0, nullptr, false,
-                     stream_out ? static_cast<uint8_t *>(out) : nullptr);
+                     stream_out ? static_cast<uint8_t *>(out) : nullptr, out_cap);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     if (!stream_out) ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));

@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(1024) inflate_reduce_kernel(const InfStatus *s
 
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets,
-                bool open_end = false, uint8_t *h_dst = nullptr);
+                bool open_end = false, uint8_t *h_dst = nullptr, uint64_t h_cap = 0);
 
 } // namespace zgpu
 
@@ -1005,19 +1005,22 @@ static int output_checksums(zgpu_engine *e, const uint8_t *d_out, uint64_t nbyte
 
 // stream_mode (compact or whole-stream calls): see inflate_reduce_kernel; h_offsets = the offsets table on the host (for res->in_used);
 // open_end: the last segment ends with a flush marker like the others, no segment has to hold the final block
-// h_dst (direct placement only): the caller's host buffer; every batch's output is copied there on the engine's copy stream while the
-// next batch is being decoded
+// h_dst (direct placement only): the caller's host buffer of h_cap bytes; every batch's output is copied there on the engine's copy stream while
+// the next batch is being decoded.  out_cap is the DEVICE buffer's room (whole chunks); no copy to the host reaches beyond h_cap, and a result that
+// does not fit h_cap is an error before anything that was not served batch by batch is copied
 int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks, uint32_t chunk_size,
                 uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode, const uint64_t *h_offsets, bool open_end,
-                uint8_t *h_dst)
+                uint8_t *h_dst, uint64_t h_cap)
 {
+    const uint64_t host_cap = h_dst ? (h_cap < out_cap ? h_cap : out_cap) : 0;
     const uint64_t last_chunk = open_end ? ~0ull : nchunks - 1;
     if (!e || !res || !d_in || !d_out || !d_offsets || nchunks == 0 || (chunk_size > kChunkMax && !(chunk_size == kWholeStream && nchunks == 1)) ||
         (chunk_size == kWholeStream && in_bytes >= (1ull << 29)))
         return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
     const bool compact = chunk_size == 0; // segments of any size: decode into slots, then concatenate
-    // (one batch has nothing to overlap with; and the copy engine path of small pageable copies behind an event has thrown inside the runtime)
+    // (one batch has nothing to overlap with.  Until round 3 these copies were bounded by the device buffer's size, not by the caller's: a buffer of
+    // exactly the decoded length was overrun by up to a chunk -- which is what "threw inside the runtime" on small calls)
     static long tohost_min = -1;
     if (tohost_min < 0) { const char *v = getenv("ZGPU_TOHOST_MIN_CHUNKS"); tohost_min = v ? atol(v) : 4097; }
     const bool to_host = h_dst && chunk_size != 0 && chunk_size <= kChunkMax && (long)nchunks >= tohost_min;
@@ -1033,7 +1036,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     uint8_t *slots = nullptr;
     if (compact) { slots = static_cast<uint8_t *>(engine_scratch2(e, (size_t)batch * kChunkMax + 256)); if (!slots) return engine_fail(e, ZGPU_MEM_ERROR, "inflate slots"); }
     res->adler32 = 1; res->crc32 = 0; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0; res->out_bytes = 0;
-    res->in_used = in_bytes; res->stream_end = 0; res->incomplete = 0;
+    res->in_used = in_bytes; res->in_used_bits = 0; res->stream_end = 0; res->incomplete = 0;
     ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 8 * sizeof(uint64_t), st));
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
@@ -1058,7 +1061,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
             const size_t b = (size_t)(c0 / batch);
             ZGPU_HIP_CHECK(hipEventRecord(engine_copy_event(e, b), st));
             if (b > 0) {
-                const uint64_t lo = (c0 - batch) * chunk_size, hi = c0 * (uint64_t)chunk_size < out_cap ? c0 * (uint64_t)chunk_size : out_cap;
+                const uint64_t lo = (c0 - batch) * chunk_size, hi = c0 * (uint64_t)chunk_size < host_cap ? c0 * (uint64_t)chunk_size : host_cap;
                 ZGPU_HIP_CHECK(hipStreamWaitEvent(engine_copy_stream(e), engine_copy_event(e, b - 1), 0));
                 if (hi > lo) ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst + lo, d_out + lo, hi - lo, hipMemcpyDeviceToHost, engine_copy_stream(e)));
             }
@@ -1066,7 +1069,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     }
     if (to_host) {
         const size_t b = (size_t)((nchunks - 1) / batch);
-        const uint64_t lo = b * (uint64_t)batch * chunk_size, hi = nchunks * (uint64_t)chunk_size < out_cap ? nchunks * (uint64_t)chunk_size : out_cap;
+        const uint64_t lo = b * (uint64_t)batch * chunk_size, hi = nchunks * (uint64_t)chunk_size < host_cap ? nchunks * (uint64_t)chunk_size : host_cap;
         ZGPU_HIP_CHECK(hipStreamWaitEvent(engine_copy_stream(e), engine_copy_event(e, b), 0));
         if (hi > lo) ZGPU_HIP_CHECK(hipMemcpyAsync(h_dst + lo, d_out + lo, hi - lo, hipMemcpyDeviceToHost, engine_copy_stream(e)));
         ZGPU_HIP_CHECK(hipStreamSynchronize(engine_copy_stream(e)));
@@ -1081,7 +1084,7 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     }
     res->out_bytes = h[0]; res->first_bad_chunk = h[1] ? (int32_t)(h[1] - 1) : -1; res->error_code = (int32_t)(int64_t)h[2]; res->error_msg = (uint32_t)h[3];
     if (h[1]) { engine_collect(e); return engine_fail(e, res->error_code, kInfMessages[res->error_msg < kMsgCount ? res->error_msg : 0]); }
-    if (h[0] > out_cap) { engine_collect(e); return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small"); }
+    if (h[0] > out_cap || (h_dst && h[0] > host_cap)) { engine_collect(e); return engine_fail(e, ZGPU_BUF_ERROR, "output capacity too small"); }
     rc_sum = output_checksums(e, d_out, h[0], out_cap, res, st);
     if (rc_sum) return rc_sum;
     if (h_dst && !to_host && h[0]) { // a host destination that was not served batch by batch
@@ -1511,20 +1514,22 @@ __global__ void __launch_bounds__(256) spec_resolve_kernel(const uint16_t *__res
 }
 
 // 0: decoded (res complete); 1: not this way (the caller uses the one-workgroup decoder); anything else: an error of the engine
+// start_bit (0..7): the deflate data begins at that bit of the first byte (a stream taken up again where an earlier call's last whole piece ended)
 static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *h_in, uint64_t in_bytes, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res,
-                            hipStream_t st, uint32_t stream_mode)
+                            hipStream_t st, uint32_t stream_mode, uint32_t start_bit = 0, bool force = false)
 {
+    // force: whatever the size (a stream that goes on at a bit offset has no other decoder: one piece is one workgroup)
     static long min_bytes = -1;
     if (min_bytes < 0) { const char *v = getenv("ZGPU_SPEC_MIN_BYTES"); min_bytes = v ? atol(v) : 128 * 1024; }
-    if ((long)in_bytes < min_bytes || in_bytes >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return 1;
-    res->adler32 = 1; res->crc32 = 0; res->in_used = in_bytes; res->stream_end = 0; res->incomplete = 0;
+    if ((!force && (long)in_bytes < min_bytes) || in_bytes >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return 1;
+    res->adler32 = 1; res->crc32 = 0; res->in_used = in_bytes; res->in_used_bits = 0; res->stream_end = 0; res->incomplete = 0;
     uint64_t spacing = (in_bytes / 4096 + 4095) & ~4095ull;
     if (spacing < 32768) spacing = 32768;
     // the finders stand four times as close as the pieces will be (each scans to the next finder at most; of what they find the host keeps starts
     // at least three quarters of `spacing` apart)
     const uint64_t fspacing = spacing / 4 < 16384 ? 16384 : (spacing / 4 + 4095) & ~4095ull;
     const uint32_t ntargets = (uint32_t)((in_bytes - 1) / fspacing);
-    if (ntargets < 3) return 1;
+    if (ntargets < 3 && !force) return 1;
     uint64_t *d_found = static_cast<uint64_t *>(engine_scratch(e, (size_t)ntargets * 16 + 64));
     if (!d_found) return engine_fail(e, ZGPU_MEM_ERROR, "inflate scratch");
     static bool opt_in = false;
@@ -1536,9 +1541,9 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
     }
     hipEvent_t ev{};
     prof_span_begin(e, st, &ev);
-    hipLaunchKernelGGL(spec_find_kernel, dim3(ntargets), dim3(64), sizeof(InflateLdsFind), st, d_in, in_bytes, fspacing, ntargets, d_found);
+    if (ntargets) hipLaunchKernelGGL(spec_find_kernel, dim3(ntargets), dim3(64), sizeof(InflateLdsFind), st, d_in, in_bytes, fspacing, ntargets, d_found);
     std::vector<uint64_t> found(2 * (size_t)ntargets);
-    ZGPU_HIP_CHECK(hipMemcpyAsync(found.data(), d_found, found.size() * 8, hipMemcpyDeviceToHost, st));
+    if (ntargets) ZGPU_HIP_CHECK(hipMemcpyAsync(found.data(), d_found, found.size() * 8, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     // starts: bit positions; kind 1 = the LEN of a stored block (a byte position; the block's header bits lie up to 10 bits in front)
     const uint64_t kStoredFlag = 1ull << 62;
@@ -1563,7 +1568,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
             if (!inside) all.emplace_back(d, (uint8_t)0);
         }
         std::sort(all.begin(), all.end());
-        starts.push_back(0); kind.push_back(0);
+        starts.push_back(start_bit); kind.push_back(0);
         for (const auto &c : all)
             if (c.first >= starts.back() + spacing * 6 && c.first + spacing * 2 < in_bytes * 8) { starts.push_back(c.first); kind.push_back(c.second); }
         starts.push_back(in_bytes * 8); kind.push_back(0);
@@ -1582,7 +1587,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
         for (uint32_t i = 0; i < nseg && i < 6; i++) fprintf(stderr, " %llu", (unsigned long long)starts[i]);
         fprintf(stderr, "\n");
     }
-    if (nseg < 3) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+    if (nseg < 3 && !force) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
     // pages: what the output can hold, or -- when the caller's buffer is far larger than this stream can fill -- eight times the input first
     uint64_t guess = in_bytes * 8 + (16u << 20);
     int repairs = 0;
@@ -1648,24 +1653,22 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
             starts.swap(fixed); kind.swap(fkind);
             nseg = (uint32_t)starts.size() - 1;
             repairs++;
-            if (nseg < 2) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+            if (nseg < 2 && !force) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
             continue;
         }
-        const uint64_t end_byte = ended ? (ends[used_seg - 1].end_bit + 7) >> 3 : 0;
+        // stream mode, every piece chained and the last one ran out of input inside a block: the stream is not all there yet, and the pieces in front
+        // of the last one are delivered -- they end at a block boundary (a bit position), where the next call takes the stream up again with their last
+        // 32 KiB as its window (inflate.c:323-371 updatewindow)
+        const bool partial = !ended && stream_mode && used_seg >= 1 && used_seg + 1 == nseg && (ends[nseg - 1].flags >> 8) == kMsgTruncated && links(ends[used_seg - 1].end_bit, used_seg);
+        const uint64_t end_bit = used_seg ? ends[used_seg - 1].end_bit : 0;
+        const uint64_t end_byte = ended ? (end_bit + 7) >> 3 : partial ? end_bit >> 3 : 0;
         if (dbg) {
             fprintf(stderr, "[spec] chain: %u of %u pieces, ended %d, total %llu, pages %u of %u, dry %d\n", used_seg, nseg, (int)ended, (unsigned long long)total, cnt[0], page_cap, (int)dry);
             for (uint32_t i = used_seg ? used_seg - 1 : 0; i < nseg && i < used_seg + 2; i++)
                 fprintf(stderr, "[spec]   piece %u: start %llu end %llu next %llu out %u flags %#x\n", i, (unsigned long long)starts[i], (unsigned long long)ends[i].end_bit,
                         (unsigned long long)starts[i + 1], ends[i].out_bytes, ends[i].flags);
         }
-        if (!ended && stream_mode && used_seg >= 1 && used_seg + 1 == nseg && (ends[nseg - 1].flags >> 8) == kMsgTruncated && links(ends[used_seg - 1].end_bit, used_seg)) {
-            // every piece chained and the last one ran out of input inside a block: the stream is not all there yet (one workgroup would say the same)
-            prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
-            engine_collect(e);
-            res->incomplete = 1; res->in_used = 0; res->out_bytes = 0; res->stream_end = 0; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0;
-            return ZGPU_OK;
-        }
-        if (!ended || (!stream_mode && end_byte != in_bytes)) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
+        if (!(ended || partial) || (!stream_mode && end_byte != in_bytes)) { prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev); return 1; }
         if (total > out_cap) {
             prof_span_end(e, st, ZGPU_STAGE_INFLATE, ev);
             res->out_bytes = total; res->first_bad_chunk = -1; res->error_code = ZGPU_BUF_ERROR; res->error_msg = 0;
@@ -1703,7 +1706,7 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
         if (dbg) fprintf(stderr, "[spec] resolved %u pages, flag %u\n", npages, flag);
         if (flag) return 1;
         res->out_bytes = total; res->first_bad_chunk = -1; res->error_code = 0; res->error_msg = 0;
-        res->in_used = end_byte; res->stream_end = stream_mode ? 1 : 0; res->incomplete = 0;
+        res->in_used = end_byte; res->in_used_bits = partial ? (uint32_t)(end_bit & 7u) : 0u; res->stream_end = (stream_mode && ended) ? 1 : 0; res->incomplete = partial ? 1 : 0;
         g_spec_done++;
         return output_checksums(e, d_out, total, out_cap, res, st);
     }
@@ -1716,12 +1719,30 @@ static int inflate_spec_run(zgpu_engine *e, const uint8_t *d_in, const uint8_t *
 // flags & ZGPU_INF_STREAM: `in` is the rest of a stream, not a delimited body: it ends where its final block ends (res->in_used,
 // res->stream_end) whatever follows, and input that stops inside a block yields the segments before it (res->incomplete).
 static int inflate_stream_host(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t flags, void *out, uint64_t out_cap, zgpu_inflate_result *res,
-                               std::vector<uint64_t> *offsets_out)
+                               std::vector<uint64_t> *offsets_out, uint32_t start_bit = 0)
 {
-    if (!e || !in || !res || in_bytes == 0) return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
+    if (!e || !in || !res || in_bytes == 0 || start_bit > 7) return engine_fail(e, ZGPU_STREAM_ERROR, "bad inflate arguments");
     ZGPU_HIP_CHECK(hipSetDevice(engine_device(e)));
     hipStream_t st = engine_stream(e);
     const uint32_t stream_mode = (flags & ZGPU_INF_STREAM) ? 1u : 0u;
+    if (start_bit) { // the stream goes on inside its first byte (behind the last whole piece of an earlier call): the pieces are the decoder that starts at a bit
+        int rc0 = engine_ensure_stage(e, in_bytes + 256, out_cap ? out_cap : 1);
+        if (rc0) return rc0;
+        uint8_t *d_in0 = engine_stage_in(e);
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_in0, in, in_bytes, hipMemcpyHostToDevice, st));
+        const int src = inflate_spec_run(e, d_in0, static_cast<const uint8_t *>(in), in_bytes, engine_stage_out(e), out_cap, res, st, stream_mode, start_bit, true);
+        if (src == ZGPU_OK) { if (out && res->out_bytes) ZGPU_HIP_CHECK(hipMemcpy(out, engine_stage_out(e), res->out_bytes, hipMemcpyDeviceToHost)); return ZGPU_OK; }
+        if (src != 1) return src;
+        // the pieces do not chain: damage, most likely.  The verdict is the one-workgroup decoder's, on a copy of the stream that starts at bit 0
+        std::vector<uint8_t> sh(in_bytes);
+        const uint8_t *p0 = static_cast<const uint8_t *>(in);
+        for (uint64_t i = 0; i < in_bytes; i++) sh[i] = (uint8_t)((p0[i] >> start_bit) | ((i + 1 < in_bytes ? p0[i + 1] : 0) << (8 - start_bit)));
+        zgpu_inflate_result r2;
+        const int rc2 = inflate_stream_host(e, sh.data(), in_bytes, flags, nullptr, out_cap, &r2, nullptr, 0);
+        if (rc2 != ZGPU_OK) { *res = r2; return rc2; }
+        if (r2.incomplete && !r2.out_bytes) { *res = r2; res->in_used = 0; res->in_used_bits = start_bit; return ZGPU_OK; } // (not all there yet: nothing taken)
+        return engine_fail(e, ZGPU_DATA_ERROR, "a stream that goes on at a bit offset did not decode in pieces");
+    }
     const uint64_t max_cand = in_bytes / 5 + 2;
     int rc = engine_ensure_stage(e, in_bytes + 64 + (max_cand + 2) * 2 * sizeof(uint64_t) + 64, out_cap ? out_cap : 1);
     if (rc) return rc;
@@ -1839,6 +1860,11 @@ int zgpu_inflate_stream_host2(zgpu_engine *e, const void *in, uint64_t in_bytes,
 {
     if (!out) return ZGPU_STREAM_ERROR;
     return inflate_stream_host(e, in, in_bytes, flags, out, out_cap, res, nullptr);
+}
+int zgpu_inflate_stream_host3(zgpu_engine *e, const void *in, uint64_t in_bytes, uint32_t start_bit, uint32_t flags, void *out, uint64_t out_cap, zgpu_inflate_result *res)
+{
+    if (!out) return ZGPU_STREAM_ERROR;
+    return inflate_stream_host(e, in, in_bytes, flags, out, out_cap, res, nullptr, start_bit);
 }
 #pragma GCC visibility pop
 }

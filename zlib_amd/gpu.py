@@ -31,7 +31,7 @@ class DeflateResult(C.Structure):
 
 class InflateResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("adler32", C.c_uint32), ("first_bad_chunk", C.c_int32),
-                ("error_code", C.c_int32), ("error_msg", C.c_uint32), ("crc32", C.c_uint32), ("reserved", C.c_uint32),
+                ("error_code", C.c_int32), ("error_msg", C.c_uint32), ("crc32", C.c_uint32), ("in_used_bits", C.c_uint32),
                 ("in_used", C.c_uint64), ("stream_end", C.c_uint32), ("incomplete", C.c_uint32)]
 
 

@@ -43,6 +43,7 @@ typedef struct {
 } gz_file;
 
 void zamd_inflate_rest(z_streamp strm, const unsigned char **p, size_t *n); /* zamd_zlib.c */
+size_t zamd_inflate_pending(z_streamp strm);                                       /* zamd_zlib.c */
 
 static int gz_destroy(gz_file *s)
 {
@@ -174,7 +175,7 @@ EXPORT int gzread(gzFile file, voidp buf, unsigned len)
             if (got == 0 && s->eof) s->err = Z_STREAM_END;
             return (int)(from_back + got);
         }
-        if (s->strm.avail_in == 0 && !s->eof) gz_fill(s);
+        if (s->strm.avail_in == 0 && !s->eof && zamd_inflate_pending(&s->strm) == 0) gz_fill(s); /* (what is decoded already goes out first) */
         const uInt in0 = s->strm.avail_in;
         const int rc = inflate(&s->strm, s->eof ? Z_FINISH : Z_NO_FLUSH);
         s->in += in0 - s->strm.avail_in;

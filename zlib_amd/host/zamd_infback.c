@@ -17,6 +17,7 @@
 struct back_state { int kind; z_stream inner; unsigned char *window; unsigned wsize; unsigned char *carry; };
 
 void zamd_inflate_rest(z_streamp strm, const unsigned char **p, size_t *n); /* zamd_zlib.c */
+size_t zamd_inflate_pending(z_streamp strm);                                       /* zamd_zlib.c */
 
 EXPORT int inflateBackInit_(z_streamp strm, int windowBits, unsigned char *window, const char *version, int stream_size)
 {
@@ -44,7 +45,7 @@ EXPORT int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, 
     z->next_out = b->window; z->avail_out = b->wsize;
     int no_more = 0;
     for (;;) {
-        if (z->avail_in == 0 && !no_more) {
+        if (z->avail_in == 0 && !no_more && zamd_inflate_pending(z) == 0) { /* (what is decoded already goes through the window first) */
             unsigned char *next = Z_NULL;
             const unsigned have = in(in_desc, &next);
             if (have == 0) no_more = 1; else { z->next_in = next; z->avail_in = have; }

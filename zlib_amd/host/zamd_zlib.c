@@ -261,6 +261,9 @@ struct internal_state {
     uint64_t produced; /* bytes decoded so far (ISIZE check) */
     size_t next_try;  /* do not try to decode again before this many unconsumed bytes have been collected */
     int pending_err;  /* a data error found behind output that has not been delivered yet: reported when it has */
+    size_t last_piece; /* inflate: the largest piece of input a call has brought so far */
+    unsigned skip_bits; /* inflate: bits of the byte at in_pos that belong to what has been decoded already (a stream without flush points is taken up
+                           again where the last whole piece ended, which is a bit position) */
     const char *pending_msg;
     int no_partial;   /* keep everything from in_pos until the stream ends in one decode (inflatePrime) */
     int prime_bits; uint32_t prime_val; /* inflatePrime */
@@ -692,7 +695,7 @@ EXPORT int inflateReset(z_streamp strm)
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->adler = 1;
     s->in.len = 0; s->in_pos = 0; s->out.len = 0; s->out_pos = 0; s->status = ST_BUSY; s->adler = 1; s->crc = 0; s->next_try = 0; s->dict.len = 0;
     s->need_dict = 0; s->have_dict = 0; s->mode = s->wrap ? IN_HEAD : IN_BODY; s->gz = 0; s->produced = 0; s->pending_err = 0; s->pending_msg = NULL;
-    s->no_partial = 0; s->prime_bits = 0; s->prime_val = 0; s->sync_have = 0; s->at_marker = 0; s->gzhead = Z_NULL;
+    s->no_partial = 0; s->prime_bits = 0; s->prime_val = 0; s->sync_have = 0; s->at_marker = 0; s->gzhead = Z_NULL; s->last_piece = 0; s->skip_bits = 0;
     return Z_OK;
 }
 EXPORT int inflateEnd(z_streamp strm)
@@ -821,11 +824,13 @@ static int decode_some(z_streamp strm, size_t out_hint)
     for (;;) {
         if (!buf_reserve(&s->out, cap)) { free(shifted); return Z_MEM_ERROR; }
         memset(&r, 0, sizeof r);
-        const int first = s->produced == 0 && s->have_dict; /* the dictionary is what the window holds in front of the first byte only */
+        /* what the window holds in front of this call's first byte (inflate.c:323-371 updatewindow): the preset dictionary, then the last 32 KiB
+         * of what earlier calls produced -- a stream whose blocks reach back across a sync flush decodes in pieces as it arrives */
+        const int first = s->dict.len != 0 && (s->have_dict || s->produced != 0);
         e = engine_checkout();
         int rc = zgpu_inflate_set_dictionary(e, first ? s->dict.p : NULL, first ? (uint32_t)s->dict.len : 0u);
         zgpu_inflate_set_checks(e, s->gz ? ZGPU_CHECK_CRC32 : ZGPU_CHECK_ADLER32); /* (the one check this stream's trailer holds: each is a pass over the output) */
-        if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host2(e, src, srcn, ZGPU_INF_STREAM, s->out.p + s->out.len, cap, &r);
+        if (rc == ZGPU_OK) rc = zgpu_inflate_stream_host3(e, src, srcn, s->prime_bits ? 0u : s->skip_bits, ZGPU_INF_STREAM, s->out.p + s->out.len, cap, &r);
         if (first) zgpu_inflate_set_dictionary(e, NULL, 0);
         zgpu_inflate_set_checks(e, ZGPU_CHECK_ADLER32 | ZGPU_CHECK_CRC32);
         engine_checkin(e);
@@ -837,12 +842,23 @@ static int decode_some(z_streamp strm, size_t out_hint)
     }
     if (s->no_partial && !r.stream_end) { s->next_try = n + n / 4 + 1; return Z_OK; } /* (all or nothing) */
     if (r.out_bytes) {
+        { /* the window for the next call: the last 32 KiB of dictionary + output so far */
+            const uint8_t *fresh = s->out.p + s->out.len; const size_t nf = (size_t)r.out_bytes;
+            if (nf >= 32768u) { s->dict.len = 0; if (!buf_put(&s->dict, fresh + (nf - 32768u), 32768u)) return Z_MEM_ERROR; }
+            else {
+                const size_t keep = s->dict.len < 32768u - nf ? s->dict.len : 32768u - nf;
+                if (keep != s->dict.len) memmove(s->dict.p, s->dict.p + (s->dict.len - keep), keep);
+                s->dict.len = keep;
+                if (!buf_put(&s->dict, fresh, nf)) return Z_MEM_ERROR;
+            }
+        }
         s->out.len += r.out_bytes;
         if (s->gz) s->crc = crc_join(s->crc, r.crc32, r.out_bytes); else s->adler = adler_join(s->adler, r.adler32, r.out_bytes);
         s->produced += r.out_bytes;
     }
     size_t used = (size_t)r.in_used;
     if (s->prime_bits) { used = used * 8 > (size_t)s->prime_bits ? (used * 8 - (size_t)s->prime_bits + 7) / 8 : 0; if (used > n) used = n; s->prime_bits = 0; }
+    s->skip_bits = r.stream_end ? 0u : r.in_used_bits;
     if (used >= 4) { const uint8_t *q = IN_PTR(s) + used - 4; s->at_marker = !r.stream_end && q[0] == 0 && q[1] == 0 && q[2] == 0xff && q[3] == 0xff; }
     s->in_pos += used;
     if (r.stream_end) s->mode = s->wrap ? IN_TRAIL : IN_DONE;
@@ -859,11 +875,17 @@ EXPORT int inflate(z_streamp strm, int flush)
     if (s->status == ST_BAD) return Z_DATA_ERROR;
     if (s->status == ST_DONE) return Z_STREAM_END;
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
-    if (s->mode != IN_DONE && strm->avail_in) {
+    size_t absorbed = 0; /* what of this call's input went into s->in: only that can be handed back through next_in */
+    /* input is taken in only while the caller's buffer can take what is decoded already: a reader with a small buffer keeps its input (as it does
+     * with the reference, which stops reading when the output is full) and the library's backlog stays bounded */
+    const size_t backlog = s->out.len - s->out_pos;
+    if (s->mode != IN_DONE && strm->avail_in && !(backlog != 0 && backlog >= strm->avail_out)) {
+        absorbed = strm->avail_in;
         if (s->in_pos && s->in_pos >= s->in.len / 2) { memmove(s->in.p, s->in.p + s->in_pos, s->in.len - s->in_pos); s->in.len -= s->in_pos; s->in_pos = 0; }
         if (!buf_put(&s->in, strm->next_in, strm->avail_in)) return Z_MEM_ERROR;
         strm->next_in += strm->avail_in; strm->total_in += strm->avail_in; strm->avail_in = 0;
     }
+    if (absorbed > s->last_piece) s->last_piece = absorbed;
     if (s->mode == IN_HEAD) {
         int rc = parse_header(strm);
         if (rc == Z_NEED_DICT || rc == Z_DATA_ERROR) return rc;
@@ -871,7 +893,12 @@ EXPORT int inflate(z_streamp strm, int flush)
     if (s->mode == IN_BODY && !s->pending_err) {
         /* Decode when the caller says this is everything (Z_FINISH), has stopped supplying input, or enough has arrived since the
          * last look.  What is complete is taken; a stream that stops inside a block simply waits for more. */
-        if (flush == Z_FINISH || in0 == 0 || IN_AVAIL(s) < 4096 || IN_AVAIL(s) >= s->next_try) {
+        const size_t undelivered = s->out.len - s->out_pos;
+        if (undelivered != 0 && undelivered >= strm->avail_out) { /* the caller's buffer is served from what is decoded already: nothing more is decoded
+                                                                     (and held) until that is gone -- memory stays O(one call) for small readers */
+        } else if (flush == Z_FINISH || in0 == 0 || IN_AVAIL(s) < 4096 || IN_AVAIL(s) >= s->next_try || (absorbed && absorbed < s->last_piece)) {
+            /* (a piece shorter than the one before it is how the last slice of a file looks: decoding it in the call that brings it lets the bytes behind
+             * the end of the stream go back to the caller, inflate.c:1114) */
             int rc = decode_some(strm, strm->avail_out);
             if (rc == Z_DATA_ERROR && s->out.len - s->out_pos != 0) { /* what was decoded before comes out first (inflate.c delivers as it goes) */
                 s->status = ST_BUSY; s->pending_err = 1; s->pending_msg = strm->msg; strm->msg = Z_NULL;
@@ -896,18 +923,18 @@ EXPORT int inflate(z_streamp strm, int flush)
             else { s->in_pos += need; s->mode = IN_DONE; }
         }
     }
+    if (s->mode == IN_DONE && absorbed) {
+        /* inflate.c:1114: the rest of the input stays with the caller -- as far as it came with THIS call, and in the call that finds the end (later
+         * calls, which only drain what is decoded, take nothing in and their next_in is left alone) */
+        size_t back = IN_AVAIL(s);
+        if (back > absorbed) back = absorbed;
+        strm->next_in -= back; strm->avail_in += (uInt)back; strm->total_in -= back; s->in.len -= back;
+    }
     deliver(strm);
     strm->adler = s->gz ? s->crc : s->adler;
     const int drained = s->out.len - s->out_pos == 0;
     if (s->pending_err && drained) return in_bad(strm, s->pending_msg);
-    if (s->mode == IN_DONE && drained) {
-        /* inflate.c:1114: the rest of the input stays with the caller -- as far as it came with this call */
-        size_t back = IN_AVAIL(s);
-        if (back > in0) back = in0;
-        strm->next_in -= back; strm->avail_in += (uInt)back; strm->total_in -= back; s->in.len -= back;
-        s->status = ST_DONE;
-        return Z_STREAM_END;
-    }
+    if (s->mode == IN_DONE && drained) { s->status = ST_DONE; return Z_STREAM_END; }
     if (flush == Z_FINISH) return Z_BUF_ERROR; /* not all input, or not enough room (inflate.c:1150-1151) */
     if (in0 == 0 && out0 == strm->avail_out) return Z_BUF_ERROR;
     return Z_OK;
@@ -921,6 +948,13 @@ __attribute__((visibility("hidden"))) void zamd_inflate_rest(z_streamp strm, con
     *p = Z_NULL; *n = 0;
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE || strm->state->mode != IN_DONE) return;
     *p = IN_PTR(strm->state); *n = IN_AVAIL(strm->state);
+}
+
+/* Library-internal (zamd_gzio.c): output decoded and not yet delivered -- a reader drains it before it feeds more of the file */
+__attribute__((visibility("hidden"))) size_t zamd_inflate_pending(z_streamp strm)
+{
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_INFLATE) return 0;
+    return strm->state->out.len - strm->state->out_pos;
 }
 
 /* one byte of the search for 00 00 FF FF (inflate.c:1245-1265): `have` bytes of the pattern matched so far */
@@ -941,7 +975,7 @@ EXPORT int inflateSync(z_streamp strm)
     if (have < 4) { s->sync_have = have; return Z_DATA_ERROR; }
     /* total_in / total_out stay; everything else starts over in the middle of the deflate data (inflate.c:1296-1301) */
     s->sync_have = 0; s->status = ST_BUSY; s->mode = IN_BODY; s->adler = 1; s->crc = 0; s->produced = 0; s->pending_err = 0; s->next_try = 0;
-    s->have_dict = 0; s->need_dict = 0; s->at_marker = 1; strm->msg = Z_NULL;
+    s->have_dict = 0; s->need_dict = 0; s->at_marker = 1; strm->msg = Z_NULL; s->dict.len = 0; s->skip_bits = 0; /* (the window starts empty, inflate.c:1296 inflateReset) */
     return Z_OK;
 }
 /* inflate.c:1313-1321: "at the end of a block generated by Z_SYNC_FLUSH or Z_FULL_FLUSH" -- here: the decoder has consumed the
