@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+_SO = os.environ.get("ZAMD_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # (ZAMD_ORACLE_LIB: the sanitizer build, tests/test_sanitizers_cpu.py)
 _lib = None
 
 

@@ -34,7 +34,7 @@ def test_directory_reader_survives_damaged_archives(tmp_path):
     member that points outside the file.  These entry points do not touch the GPU, so this runs in the CPU suite (a crash would end the run)."""
     import ctypes as C
     import random
-    lib = os.path.join(ROOT, "zlib_amd", "libzamd_z.so")
+    lib = os.environ.get("ZAMD_Z_LIB") or os.path.join(ROOT, "zlib_amd", "libzamd_z.so")  # (ZAMD_Z_LIB: the sanitizer build)
     if not os.path.exists(lib):
         pytest.skip("host library not built")
     L = C.CDLL(lib)
