@@ -132,6 +132,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     eng = zlib_amd.Engine(local)
+    comm = None
+    if world > 1:
+        def exchange_id(b):  # rank 0's RCCL id to everybody, over the group that exists for the barrier
+            t = torch.tensor(list(b), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            return bytes(t.cpu().tolist())
+        comm = gpu.Comm(local, world, rank, exchange_id)
     kind = 0 if a.workload == "silesia-mix" else 1
     seed = 0x5EED5117 if kind == 0 else 0x10C7E47
     nchunks = int(a.gib * 2**30) // 65536
@@ -157,9 +164,11 @@ def main():
                                  lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
         state["res"] = res
         nonlocal gather_buf
-        if rank == 0 and gather_buf is None:
-            gather_buf = torch.empty(int(cap * world * 0.6) + 4096, dtype=torch.uint8, device=dev)
-        stream_t, total = shard.gather_stream(dst[: res.out_bytes], res.adler32, nbytes, a.level, out=gather_buf)
+        # the C library's RCCL gather (include/zamd_gpu.h zgpu_deflate_gather): sizes first, so that rank 0's buffer is exactly as large as the stream
+        table, total = comm.sizes(res.out_bytes, res.adler32, nbytes, stream=stream)
+        if rank == 0 and (gather_buf is None or gather_buf.numel() < total):
+            gather_buf = torch.empty(total + (total >> 4), dtype=torch.uint8, device=dev)
+        comm.gather(dst.data_ptr(), table, a.level, gather_buf.data_ptr() if rank == 0 else None, gather_buf.numel() if rank == 0 else 0, stream=stream)
         state["gathered"] = total
 
     def inflate_step():

@@ -93,6 +93,25 @@ typedef struct {
     uint32_t incomplete;  /* the input stops inside a block: out_bytes / in_used cover the segments in front of it (possibly none) */
 } zgpu_inflate_result;
 
+/* ---- multi-GPU: the per-rank raw bodies gathered into ONE RFC 1950 stream on rank 0 over RCCL / xGMI (zlib_amd/csrc/zgpu_comm.hip) ----
+ * One process per GPU; rank r compresses its contiguous chunk range with zgpu_deflate_device (flags = ZGPU_F_FINAL on the last rank only, no
+ * wrapper) and the only exchange is this gather.  The reference has no distributed path.  RCCL is dlopen()ed by the first call here.
+ *   rank 0: zgpu_comm_unique_id(id); the 128 bytes reach the other ranks by any channel; every rank: zgpu_comm_create(device, world, rank, id, &c);
+ *   per stream, every rank: zgpu_deflate_gather_sizes (an all-gather of three u64 per rank: rank 0 learns the exact size of the stream),
+ *   then zgpu_deflate_gather (one send per peer; on rank 0 one receive per peer at its offset, all in one group). */
+typedef struct zgpu_comm zgpu_comm;
+#define ZGPU_COMM_ID_BYTES 128
+int zgpu_comm_unique_id(void *id128);
+int zgpu_comm_create(int device, int world, int rank, const void *id128, zgpu_comm **out);
+void zgpu_comm_destroy(zgpu_comm *c);
+const char *zgpu_comm_error(void); /* the calling thread's last failure */
+/* table: world x {body bytes, Adler-32, input bytes}; offsets[r] = where rank r's body starts in the stream (offsets[0] = 2),
+ * offsets[world] = where the 4-byte trailer goes, *total = the stream's length */
+void zgpu_gather_layout(int world, const uint64_t *table, uint64_t *offsets, uint64_t *total);
+int zgpu_deflate_gather_sizes(zgpu_comm *c, uint64_t body_bytes, uint32_t adler32, uint64_t in_bytes, uint64_t *table, uint64_t *total, void *hip_stream);
+int zgpu_deflate_gather(zgpu_comm *c, const void *d_body, const uint64_t *table, int level, void *d_out, uint64_t out_cap, uint32_t *adler_out,
+                        void *hip_stream);
+
 /* ---- engine lifetime ---- */
 int zgpu_device_count(void);
 int zgpu_engine_create(int device, zgpu_engine **out);

@@ -118,3 +118,35 @@ def test_rccl_gather_world1_on_device_tensors():
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_gather_world1_through_the_c_abi():
+    """The same exchange behind the C ABI (include/zamd_gpu.h zgpu_comm_*, zgpu_deflate_gather: RCCL opened by the library itself, no torch.distributed):
+    world size 1 -- id, communicator, the all-gather of the sizes, exact sizing, framing on the device -- must give the engine's one-call stream."""
+    import torch
+    import zlib_amd
+    from zlib_amd import gpu
+    from oracle import corpus_py as CP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    eng = zlib_amd.Engine(0)
+    comm = gpu.Comm(0, 1, 0, lambda b: b)
+    try:
+        data = CP.chunks(CP.KIND_SILESIA, 9, 80)
+        src = torch.from_numpy(data.copy()).to(dev)
+        cap = eng.L.zgpu_deflate_bound(src.numel(), 65536)
+        body = torch.empty(cap, dtype=torch.uint8, device=dev)
+        whole = torch.empty(cap, dtype=torch.uint8, device=dev)
+        for level in (1, 6):
+            res = eng.deflate_device(src.data_ptr(), src.numel(), level, body.data_ptr(), cap, flags=gpu.F_FINAL)
+            table, total = comm.sizes(res.out_bytes, res.adler32, src.numel())
+            assert [int(x) for x in table] == [res.out_bytes, res.adler32, src.numel()] and total == res.out_bytes + 6
+            out = torch.zeros(total, dtype=torch.uint8, device=dev)  # exactly as large as the stream
+            adler = comm.gather(body.data_ptr(), table, level, out.data_ptr(), total)
+            res2 = eng.deflate_device(src.data_ptr(), src.numel(), level, whole.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP)
+            assert total == res2.out_bytes and adler == res2.adler32 and torch.equal(out, whole[: total])
+            with pytest.raises(zlib_amd.EngineError):  # a buffer one byte short is refused, nothing is received into it
+                comm.gather(body.data_ptr(), table, level, out.data_ptr(), total - 1)
+    finally:
+        comm.close()
+        eng.close()

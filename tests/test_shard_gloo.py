@@ -94,3 +94,19 @@ def test_inflate_partition_decodes_disjoint_ranges_of_one_stream():
                 out[o0 + k * 65536: o0 + k * 65536 + len(dec)] = dec
                 covered += len(dec)
         assert covered == len(data) and bytes(out) == data, world
+
+
+def test_gather_layout_is_the_c_librarys_arithmetic():
+    """Where every rank's body lands in the gathered stream: zgpu_gather_layout (the arithmetic zgpu_deflate_gather uses on the GPUs) against the
+    obvious prefix sums, for empty bodies too."""
+    import random
+    from zlib_amd import gpu
+    rnd = random.Random(5)
+    for world in range(1, 9):
+        for _ in range(50):
+            table = [[rnd.choice([0, 1, rnd.randrange(1 << 34)]), rnd.randrange(1 << 32), rnd.randrange(1 << 36)] for _ in range(world)]
+            offs, total = gpu.gather_layout(table)
+            want = [2]
+            for r in range(world):
+                want.append(want[-1] + table[r][0])
+            assert offs == want and total == want[-1] + 4

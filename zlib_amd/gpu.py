@@ -74,6 +74,16 @@ def load_library():
     L.zgpu_inflate_host.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
     L.zgpu_inflate_find_chunks_host.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64)]
     L.zgpu_inflate_stream_host2.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(InflateResult)]
+    L.zgpu_inflate_stream_host3.argtypes = [vp, vp, u64, u32, u32, vp, u64, C.POINTER(InflateResult)]
+    L.zgpu_comm_unique_id.argtypes = [vp]
+    L.zgpu_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.zgpu_comm_destroy.argtypes = [vp]
+    L.zgpu_comm_destroy.restype = None
+    L.zgpu_comm_error.restype = C.c_char_p
+    L.zgpu_gather_layout.argtypes = [C.c_int, vp, vp, C.POINTER(u64)]
+    L.zgpu_gather_layout.restype = None
+    L.zgpu_deflate_gather_sizes.argtypes = [vp, u64, u32, u64, vp, C.POINTER(u64), vp]
+    L.zgpu_deflate_gather.argtypes = [vp, vp, vp, C.c_int, vp, u64, C.POINTER(u32), vp]
     L.zgpu_inflate_spec_count.argtypes = [C.c_int]
     L.zgpu_inflate_spec_count.restype = u64
     L.zgpu_inflate_message.argtypes = [u32]
@@ -267,3 +277,57 @@ class Engine:
             self.L.zgpu_profile_get(self.h, i, C.byref(ms), C.byref(n))
             out[name] = (ms.value, n.value)
         return out
+
+
+def gather_layout(table):
+    """table: world rows of (body bytes, Adler-32, input bytes).  Returns (offsets[world + 1], total): where every rank's body starts in the gathered
+    stream, where the trailer goes, the stream's length -- the C library's arithmetic (zgpu_gather_layout), which the RCCL gather itself uses."""
+    import numpy as np
+    L = load_library()
+    t = np.ascontiguousarray(table, dtype=np.uint64).reshape(-1, 3)
+    offs = np.zeros(len(t) + 1, dtype=np.uint64)
+    total = C.c_uint64(0)
+    L.zgpu_gather_layout(len(t), t.ctypes.data, offs.ctypes.data, C.byref(total))
+    return [int(x) for x in offs], int(total.value)
+
+
+class Comm:
+    """The RCCL communicator of the C library (include/zamd_gpu.h zgpu_comm_*): one per process and GPU.  `exchange_id` hands rank 0's 128-byte id
+    to the other ranks -- any channel will do; bench.py uses the torch.distributed group it has for its barrier."""
+
+    def __init__(self, device, world, rank, exchange_id):
+        import numpy as np
+        self.L = load_library()
+        self.world, self.rank = world, rank
+        ident = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            rc = self.L.zgpu_comm_unique_id(ident.ctypes.data)
+            if rc != 0:
+                raise EngineError(rc, self.L.zgpu_comm_error().decode())
+        ident = np.frombuffer(exchange_id(ident.tobytes()), dtype=np.uint8).copy()
+        h = C.c_void_p()
+        rc = self.L.zgpu_comm_create(device, world, rank, ident.ctypes.data, C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self.L.zgpu_comm_error().decode())
+        self.h = h
+
+    def sizes(self, body_bytes, adler, in_bytes, stream=None):
+        import numpy as np
+        table = np.zeros(self.world * 3, dtype=np.uint64)
+        total = C.c_uint64(0)
+        rc = self.L.zgpu_deflate_gather_sizes(self.h, body_bytes, adler, in_bytes, table.ctypes.data, C.byref(total), stream)
+        if rc != 0:
+            raise EngineError(rc, self.L.zgpu_comm_error().decode())
+        return table, int(total.value)
+
+    def gather(self, d_body, table, level, d_out=None, out_cap=0, stream=None):
+        adler = C.c_uint32(0)
+        rc = self.L.zgpu_deflate_gather(self.h, d_body, table.ctypes.data, level, d_out, out_cap, C.byref(adler), stream)
+        if rc != 0:
+            raise EngineError(rc, self.L.zgpu_comm_error().decode())
+        return int(adler.value)
+
+    def close(self):
+        if self.h:
+            self.L.zgpu_comm_destroy(self.h)
+            self.h = None

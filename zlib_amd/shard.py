@@ -10,7 +10,9 @@ raw-deflate body of its own (only the last rank's last chunk carries BFINAL), an
   3. rank 0 writes the 2-byte zlib header in front and the big-endian Adler-32 of the whole input behind, combining
      the per-rank checksums (Adler-32 of a concatenation: a = a1 + a2 - 1, b = b1 + b2 + len2 * (a1 - 1), mod 65521).
 
-Works with any backend (nccl on GPUs, gloo on CPU tensors -- the latter is what tests/test_shard_gloo.py runs).
+Works with any backend (nccl on GPUs, gloo on CPU tensors -- the latter is what tests/test_shard_gloo.py runs).  The same exchange without
+torch, behind the C ABI: include/zamd_gpu.h zgpu_comm_* / zgpu_deflate_gather (zlib_amd/csrc/zgpu_comm.hip), which bench.py --gpus N uses; this
+module stays as its torch.distributed twin (gloo on the CPU) and shares the offset arithmetic with it (zgpu_gather_layout).
 """
 import torch
 import torch.distributed as dist
@@ -63,7 +65,9 @@ def gather_stream(body: torch.Tensor, adler: int, in_bytes: int, level: int, out
     dist.all_gather_into_tensor(allv, mine, group=group)
     rows = allv.view(world, 3).tolist()
     sizes = [r[0] for r in rows]
-    total = 2 + sum(sizes) + 4
+    from . import gpu
+    offsets, total = gpu.gather_layout(rows)  # (the C library's arithmetic: zgpu_gather_layout, which the RCCL gather of zgpu_comm.hip uses too)
+    assert offsets[0] == 2 and total == 2 + sum(sizes) + 4
     if rank != 0:
         if body.numel():
             for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, body, 0, group)]):
