@@ -1291,6 +1291,7 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
     prof_span_begin(prof, st, &ev);
     launch_parse(g, cfg, recs, tokens, meta, st);
+
     prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
     return adler_done;
 }
