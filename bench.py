@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--gib", type=float, default=4.0, help="GiB of input per GPU")
     ap.add_argument("--workload", default="silesia-mix", choices=["silesia-mix", "log-text"])
-    ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel", "sorted", "walk", "fast"])
+    ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel", "sorted", "walk", "fast", "fastwin"])
     ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,6 +113,30 @@ def cpu_baseline(sample, level, threads, op="deflate"):
                 what, len(sample) >> 20, dt, "" if op == "inflate" else ", ratio %.3f" % (len(sample) / out_bytes))}
 
 
+def check_sampled_chunks(torch, dst, offs, nchunks, rank_chunk0, level, workload, nsample=64):
+    """The claim "bit-exact" checked in the run that makes it: `nsample` of the chunks the committed fixture samples (tests/golden/corpus_*.json: the
+    REFERENCE's output length and SHA-256 per chunk at levels 1 / 6 / 9, generated by oracle/gen_golden.py from the compiled reference) are cut out of the
+    stream just produced and compared.  Returns the number checked, or exits.  (None: no fixture for this level or workload.)"""
+    import hashlib
+    name = {"silesia-mix": "corpus_silesia.json", "log-text": "corpus_logtext.json"}[workload]
+    col = {1: 2, 6: 4, 9: 6}.get(level)
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if col is None or not os.path.exists(path):
+        return None
+    rows = [r for r in json.load(open(path))["rows"] if rank_chunk0 <= r[0] < rank_chunk0 + nchunks - 1]  # (the last chunk carries BFINAL: not the fixture's variant)
+    rows = rows[:: max(1, len(rows) // nsample)][:nsample]
+    if not rows:
+        return None
+    idx = torch.tensor([r[0] - rank_chunk0 for r in rows], dtype=torch.int64, device=offs.device)
+    lo = offs[idx].cpu().tolist()
+    hi = offs[idx + 1].cpu().tolist()
+    for r, a, b in zip(rows, lo, hi):
+        seg = dst[a:b].cpu().numpy().tobytes()
+        if [len(seg), hashlib.sha256(seg).hexdigest()[:16]] != r[col:col + 2]:
+            sys.exit("chunk %d at level %d differs from the reference's output (%d bytes, fixture %d)" % (r[0], level, len(seg), r[col]))
+    return len(rows)
+
+
 def main():
     a = parse()
     import torch
@@ -148,7 +172,7 @@ def main():
     cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
     dst = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
-    lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL, "sorted": gpu.LZ_SORTED, "walk": gpu.LZ_WALK, "fast": gpu.LZ_FAST}[a.lz]
+    lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL, "sorted": gpu.LZ_SORTED, "walk": gpu.LZ_WALK, "fast": gpu.LZ_FAST, "fastwin": gpu.LZ_FASTWIN}[a.lz]
     stream = torch.cuda.current_stream().cuda_stream
     gather_buf = None
     state = {}
@@ -231,7 +255,11 @@ def main():
         # separate passes, scripts/prof_cache.sh); the committed counters are quoted when they are for this very workload and kernel.
         traffic, traffic_src, limiter = None, None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tj = {}
+            for name in ("r02_traffic.json", "r03_traffic.json"):  # (the later round's counters replace the earlier ones for the same kernel and workload)
+                fn = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(fn):
+                    tj.update(json.load(open(fn)))
             key = "%s-L%d-%s-%.0fgib-%s" % (op, level, a.workload, in_bytes / 2**30, dom)
             if key in tj and (op != "deflate" or a.lz == "auto"):
                 traffic, traffic_src, limiter = tj[key]["traffic_bytes_per_launch"], tj[key]["source"], tj[key].get("limiter")
@@ -256,7 +284,9 @@ def main():
             "config": {"workload": "%s %.2f GiB per GPU, 64 KiB independent chunks, level %d, bit-exact vs zlib 1.2.3" % (
                 a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
-                "gathered_bytes": int(state.get("gathered", res.out_bytes))},
+                "gathered_bytes": int(state.get("gathered", res.out_bytes)),
+                "chunks_checked_against_reference_hashes": (check_sampled_chunks(torch, dst, offs, nchunks, rank * nchunks, a.level, a.workload)
+                                                            if a.op == "deflate" else None)},
             "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),
         }
     # ---- the other configurations of BASELINE.json on the same input, outside the timed region of the headline (N = 1 only):
@@ -264,18 +294,33 @@ def main():
     if world == 1 and a.op == "deflate" and not a.no_extras:
         extra = {}
         z_len = state["res"].out_bytes
+        offs2 = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+
+        def leg_cpu_baseline(level, op):
+            # the reference on the host cores for this leg, on a sample sized to a few seconds (level 9 is 3.5 times slower per byte than level 6)
+            if a.no_cpu_baseline:
+                return None
+            mib = {1: 512, 9: 96}.get(level, 256) if op == "deflate" else 512
+            sample = src[: min(nbytes, mib << 20)].cpu().numpy().tobytes()
+            threads, host_cpus = usable_cores()
+            cb = cpu_baseline(sample, level, threads, op)
+            cb["host_logical_cpus"] = host_cpus
+            cb["cpu_model"] = cpu_model()
+            return cb
 
         def one_level(level, steps):
             st = {}
 
             def f():
                 st["res"] = eng.deflate_device(src.data_ptr(), nbytes, level, dst2.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
-                                               lz_impl=gpu.LZ_AUTO, stream=stream)
+                                               lz_impl=gpu.LZ_AUTO, d_offsets=offs2.data_ptr(), stream=stream)
             d, pr = timed(f, steps, 1)
             return {"metric": "GiB/s raw input compressed (deflate level %d)" % level, "value": round(nbytes * steps / d / 2**30, 4),
                     "unit": "GiB/s", "steps": steps, "warmup": 1, "ms_per_step": round(d / steps * 1e3, 3),
                     "compression_ratio": round(nbytes / st["res"].out_bytes, 4),
-                    "roofline": roofline_of(pr, steps, nbytes, st["res"].out_bytes, "deflate", level)}
+                    "chunks_checked_against_reference_hashes": check_sampled_chunks(torch, dst2, offs2, nchunks, 0, level, a.workload),
+                    "roofline": roofline_of(pr, steps, nbytes, st["res"].out_bytes, "deflate", level),
+                    "cpu_baseline": leg_cpu_baseline(level, "deflate")}
 
         # config 4: the stream the headline produced, back to the original bytes (checked)
         src2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -292,12 +337,13 @@ def main():
         extra["inflate"] = {"metric": "GiB/s raw output decompressed (inflate of the level-%d stream)" % a.level,
                             "value": round(nbytes * a.steps / d / 2**30, 4), "unit": "GiB/s", "steps": a.steps, "warmup": 1,
                             "ms_per_step": round(d / a.steps * 1e3, 3), "bytes_equal": True,
-                            "roofline": roofline_of(pr, a.steps, nbytes, z_len, "inflate", a.level)}
+                            "roofline": roofline_of(pr, a.steps, nbytes, z_len, "inflate", a.level),
+                            "cpu_baseline": leg_cpu_baseline(a.level, "inflate")}
         del src2
         dst2 = torch.empty(cap, dtype=torch.uint8, device=dev)
         extra["level1"] = one_level(1, a.steps)
         extra["level9"] = one_level(9, max(1, a.steps // 2))  # (the deepest chains: fewer steps, stated in "steps")
-        del dst2
+        del dst2, offs2
         # the zlib-API path hands over host buffers: H2D of the input, the same kernels, D2H of the stream (SURVEY.md 8d "end-to-end")
         import ctypes as C
         import numpy as np
