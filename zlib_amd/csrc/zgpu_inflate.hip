@@ -48,7 +48,10 @@ static const char *const kInfMessages[kMsgCount] = {
 struct InfStatus { int32_t code; uint32_t msg; uint32_t out_bytes; uint32_t used; }; // used: input bytes up to the end of the last block | final block seen << 31
 
 constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 256;
-constexpr uint32_t kOutRing = 32768, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
+#ifndef ZGPU_INF_RING
+#define ZGPU_INF_RING 32768
+#endif
+constexpr uint32_t kOutRing = ZGPU_INF_RING, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
 
 // Decoding table entries of the literal/length and distance codes carry everything the symbol loop needs:
 //   bits 0-3 code length, 4-7 extra bits, 8 literal, 9 end of block, 10 length/distance, 11 invalid symbol, 16-31 byte / base value
