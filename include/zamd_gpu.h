@@ -65,7 +65,9 @@ typedef struct {
     int32_t lz_impl;     /* ZGPU_LZ_* */
     int32_t strategy;    /* 0 Z_DEFAULT_STRATEGY, 1 Z_FILTERED, 2 Z_HUFFMAN_ONLY, 3 Z_RLE, 4 Z_FIXED (qcsrc/deflate.c:1485-1497,
                             1594-1611; trees.c:986).  Not served by ZGPU_LZ_PARALLEL. */
-    int32_t reserved;
+    uint32_t prime;      /* deflatePrime (qcsrc/deflate.c:404-413): (nbits << 16) | value, nbits 0..16.  The first chunk of the call starts behind these
+                            bits (its blocks are shifted, the padding of its stored blocks and of its end moves with them).  Not with a
+                            wrapper flag.  0: none. */
 } zgpu_deflate_params;
 
 typedef struct {

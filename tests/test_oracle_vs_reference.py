@@ -1,5 +1,8 @@
 """Pins the CPU restatement directly to the compiled reference (oracle/_ref/libzref.so).  Skipped when
 that build is absent (a checkout without /root/reference and without a prebuilt _ref/)."""
+import ctypes as C
+import os
+
 import pytest
 
 from oracle import cases, corpus_py as CP, oracle_py as O, refzlib as R
@@ -79,3 +82,17 @@ def test_checksums_match_reference():
         a = (a & 0xFFFF) % 65521 | ((a >> 16) % 65521) << 16
         b = (b & 0xFFFF) % 65521 | ((b >> 16) % 65521) << 16
         assert O.adler32_combine(a, b, n) == L.adler32_combine(a, b, n)
+
+
+def test_prime_golden_file_is_what_the_reference_writes_now():
+    """tests/golden/prime_kat.json against the compiled reference (oracle/gen_golden_prime.py made it)."""
+    import hashlib
+    import json
+    from oracle import gen_golden_prime as G
+    L = R.lib()
+    L.deflatePrime.argtypes = [C.POINTER(R.ZStream), C.c_int, C.c_int]
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prime_kat.json")))
+    assert len(kat) == len(G.INPUTS) * len(G.LEVELS) * len(G.PRIMES)
+    for c in kat[::5]:
+        z = G.ref_primed(L, cases.make(c["kind"], c["n"], c["seed"]), c["level"], c["wbits"], tuple(c["prime"]), tuple(c["mid"]) if c["mid"] else None)
+        assert len(z) == c["len"] and hashlib.sha256(z).hexdigest()[:16] == c["sha"]

@@ -55,6 +55,7 @@ struct ChunkGeom {
     uint32_t all_final;      // every chunk is a complete stream of its own
     uint32_t pos0_mode;      // 0 none, 1 chunks other than global chunk 0, 2 all chunks are position-0 matchable
     uint32_t skip0;          // preset dictionary: global chunk 0 starts with this many bytes that are window content, not data
+    uint32_t prime;          // deflatePrime: (nbits << 16) | value, the bits global chunk 0 starts behind
 };
 __device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, uint32_t &n)
 {
@@ -64,6 +65,7 @@ __device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, 
 }
 __device__ inline bool chunk_is_final(const ChunkGeom &g, uint32_t c) { return g.all_final || g.chunk0 + c == g.final_chunk; }
 __device__ inline uint32_t chunk_skip(const ChunkGeom &g, uint32_t c) { return g.chunk0 + c == 0 ? g.skip0 : 0u; }
+__device__ inline uint32_t chunk_prime(const ChunkGeom &g, uint32_t c) { return g.chunk0 + c == 0 ? g.prime : 0u; }
 __device__ inline uint32_t chunk_base(const ChunkGeom &g, uint32_t c) { return (g.pos0_mode == 2 || (g.pos0_mode == 1 && g.chunk0 + c != 0)) ? 3u : 0u; }
 
 // token: bits 0..7 = literal byte or (match length - 3); bits 8..23 = match distance (0 for a literal)

@@ -183,6 +183,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (chunk_size > kChunkMax) return fail(e, ZGPU_STREAM_ERROR, "chunk_size must be 1..65536");
     if ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) && !(p->flags & ZGPU_F_FINAL)) return fail(e, ZGPU_STREAM_ERROR, "a wrapper needs FINAL");
     if ((p->flags & ZGPU_F_ZLIB_WRAP) && (p->flags & ZGPU_F_GZIP_WRAP)) return fail(e, ZGPU_STREAM_ERROR, "one wrapper at a time");
+    if (p->prime && ((p->prime >> 16) > 16 || (p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)))) return fail(e, ZGPU_STREAM_ERROR, "prime: at most 16 bits, no wrapper");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
     if (p->strategy < 0 || p->strategy > (int)kFixed) return fail(e, ZGPU_STREAM_ERROR, "strategy must be 0..4");
     LevelCfg cfg = level_cfg(p->level);
@@ -263,6 +264,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     g.all_final = (d_seg && (p->flags & ZGPU_F_FINAL)) ? 1u : 0u;
     g.pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
     g.skip0 = skip0;
+    g.prime = (p->prime >> 16) ? ((p->prime & 0xffff0000u) | (p->prime & ((1u << (p->prime >> 16)) - 1u))) : 0u;
     const uint64_t body_cap = tail_bytes ? (out_cap >= head_bytes + tail_bytes ? out_cap - tail_bytes : 0) : out_cap;
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;

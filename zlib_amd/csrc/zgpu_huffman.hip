@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
     const bool final_chunk_here = chunk_is_final(g, c);
     const uint32_t nblocks = ntok / kBlockTokens + 1;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
-    if (tid == 0) { sh_bitpos = 0; sh_carry = 0; }
+    if (tid == 0) { const uint32_t pr = chunk_prime(g, c); sh_bitpos = pr >> 16; sh_carry = pr & 0xffffu; } // (deflatePrime: bi_valid and bi_buf as the first block finds them, deflate.c:411-412)
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {

@@ -21,7 +21,7 @@ class EngineError(RuntimeError):
 
 class _Params(C.Structure):
     _fields_ = [("level", C.c_int32), ("chunk_size", C.c_uint32), ("flags", C.c_uint32), ("lz_impl", C.c_int32),
-                ("strategy", C.c_int32), ("reserved", C.c_int32)]
+                ("strategy", C.c_int32), ("prime", C.c_uint32)]
 
 
 class DeflateResult(C.Structure):
@@ -154,7 +154,7 @@ class Engine:
         return out[: res.out_bytes].tobytes()
 
     # ---- deflate ----
-    def deflate_host(self, data, level, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO, want_offsets=False, strategy=0):
+    def deflate_host(self, data, level, flags=F_FINAL | F_ZLIB_WRAP, chunk_size=CHUNK, lz_impl=LZ_AUTO, want_offsets=False, strategy=0, prime=(0, 0)):
         """data: bytes-like or numpy uint8 array.  Returns bytes (and the chunk offsets when asked)."""
         import numpy as np
         arr = np.frombuffer(data, dtype=np.uint8) if not hasattr(data, "ctypes") else data
@@ -163,7 +163,7 @@ class Engine:
         out = np.empty(cap, dtype=np.uint8)
         nchunks = max(1, (n + chunk_size - 1) // chunk_size)
         offs = np.zeros(nchunks + 1, dtype=np.uint64)
-        p = _Params(level, chunk_size, flags, lz_impl, strategy, 0)
+        p = _Params(level, chunk_size, flags, lz_impl, strategy, (prime[0] << 16) | (prime[1] & 0xffff))  # prime = (nbits, value): deflatePrime
         res = DeflateResult()
         src = arr.ctypes.data if n else None
         self._check(self.L.zgpu_deflate_host(self.h, src, n, C.byref(p), out.ctypes.data, cap,

@@ -246,6 +246,7 @@ struct internal_state {
     size_t out_pos;   /* first undelivered byte of out */
     int trailer_done; /* deflate: Adler trailer already appended */
     int any_block;    /* deflate: at least one chunk has been emitted */
+    uint32_t dprime;  /* deflatePrime: (nbits << 16) | value, waiting for the next chunk that is emitted */
     uint32_t adler;   /* Adler-32 of the uncompressed data that went through the GPU (deflate) / was produced (inflate) */
     uint32_t crc;     /* the same for CRC-32 (gzip wrapper, wrap == 2) */
     bytebuf dict;     /* preset dictionary: deflate, the bytes the window receives until the first chunk is out; inflate, as set */
@@ -343,7 +344,7 @@ EXPORT int deflateReset(z_streamp strm)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     strm->total_in = strm->total_out = 0; strm->msg = Z_NULL; strm->data_type = Z_UNKNOWN;
-    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0; s->dict.len = 0; s->dict_pending = 0;
+    s->in.len = 0; s->out.len = 0; s->out_pos = 0; s->trailer_done = 0; s->any_block = 0; s->dict.len = 0; s->dict_pending = 0; s->dprime = 0; /* (_tr_init, trees.c:401-402) */
     s->tuned = 0; /* lm_init: the level's own parameters again (deflate.c:380, 1009-1012) */
     s->status = s->wrap ? ST_INIT : ST_BUSY; s->last_flush = Z_NO_FLUSH;
     s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
@@ -397,13 +398,17 @@ EXPORT int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_l
     s->tuned = 1; s->tune[0] = (uint32_t)good_length; s->tune[1] = (uint32_t)max_lazy; s->tune[2] = (uint32_t)nice_length; s->tune[3] = (uint32_t)max_chain;
     return Z_OK;
 }
-/* deflate.c:404-413.  A stream that starts inside a byte moves the alignment padding of every stored block and of the flush
- * marker of the first chunk; the chunk kernels start at a byte boundary, so only the trivial request is served. */
+/* deflate.c:404-413: bi_valid = bits, bi_buf = value's low bits -- the next block starts behind them.  The chunk streams end at byte boundaries
+ * (full flush), so the bits go in front of the next chunk that is emitted; the engine starts that chunk's first block inside the byte and the
+ * padding of its stored blocks and of its end moves with it, as in the reference.  Input that is still waiting for its chunk to fill would
+ * come out BEHIND the bits here but has, in the reference, partly been emitted already: that case is refused. */
 EXPORT int deflatePrime(z_streamp strm, int bits, int value)
 {
-    (void)value;
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
-    return bits == 0 ? Z_OK : Z_STREAM_ERROR;
+    struct internal_state *s = strm->state;
+    if (bits < 0 || bits > 16 || s->in.len != 0 || s->status == ST_FINISH) return Z_STREAM_ERROR;
+    s->dprime = bits ? ((uint32_t)bits << 16) | ((uint32_t)value & ((1u << bits) - 1u)) : 0u;
+    return Z_OK;
 }
 /* deflate.c:393-401 */
 EXPORT int deflateSetHeader(z_streamp strm, gz_headerp head)
@@ -434,12 +439,16 @@ EXPORT int deflateCopy(z_streamp dest, z_streamp source) { return state_copy(des
 /* level 0 needs no match finder or entropy coder: stored blocks are framing.  One chunk = the bytes the reference's
  * deflate_stored emits for a fresh stream of that chunk (deflate.c:1390-1439): blocks of at most 65531 bytes, the rest,
  * then the flush marker or, on the last chunk, the final bit. */
-static int stored_block(bytebuf *out, const uint8_t *src, size_t len, int last)
+static int stored_block(bytebuf *out, const uint8_t *src, size_t len, int last, uint32_t *prime)
 {
-    const uint8_t h[5] = {(uint8_t)(last ? 1 : 0), (uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
-    return buf_put(out, h, 5) && buf_put(out, src, len);
+    /* the 3 header bits behind whatever deflatePrime left in the bit buffer, then bi_windup (trees.c:869-877, 1184-1204) */
+    const uint32_t pb = *prime >> 16, bits = (*prime & 0xffffu) | ((uint32_t)(last ? 1 : 0) << pb), nh = (pb + 3 + 7) / 8;
+    const uint8_t h[7] = {(uint8_t)bits, (uint8_t)(bits >> 8), (uint8_t)(bits >> 16)};
+    const uint8_t l[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
+    *prime = 0;
+    return buf_put(out, h, nh) && buf_put(out, l, 4) && buf_put(out, src, len);
 }
-static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final)
+static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final, uint32_t *prime)
 {
     size_t nchunks = n ? (n + CHUNK - 1) / CHUNK : 1;
     for (size_t k = 0; k < nchunks; k++) {
@@ -449,9 +458,9 @@ static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final)
         /* what deflate_stored emits for a fresh stream of `len` bytes: a block is cut at 65531 bytes (pending_buf_size - 5,
          * deflate.c:1397-1402,1420-1427) or as soon as it reaches MAX_DIST = 32506 bytes (:1431-1434), and the flush at the end
          * then closes whatever is left -- an EMPTY block after a MAX_DIST cut that took everything */
-        if (len > 65531) ok = stored_block(out, src + lo, 65531, 0) && stored_block(out, src + lo + 65531, len - 65531, last);
-        else if (len >= 32506) ok = stored_block(out, src + lo, len, 0) && stored_block(out, src + lo, 0, last);
-        else ok = stored_block(out, src + lo, len, last);
+        if (len > 65531) ok = stored_block(out, src + lo, 65531, 0, prime) && stored_block(out, src + lo + 65531, len - 65531, last, prime);
+        else if (len >= 32506) ok = stored_block(out, src + lo, len, 0, prime) && stored_block(out, src + lo, 0, last, prime);
+        else ok = stored_block(out, src + lo, len, last, prime);
         if (!ok) return 0;
         if (!last) { static const uint8_t marker[5] = {0, 0, 0, 0xff, 0xff}; if (!buf_put(out, marker, 5)) return 0; }
     }
@@ -470,7 +479,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
         const int first_final = final && take == n;
         s->dict_pending = 0;
         if (s->level == 0) {
-            if (!stored_chunks(&s->out, src, take, first_final)) return Z_MEM_ERROR;
+            if (!stored_chunks(&s->out, src, take, first_final, &s->dprime)) return Z_MEM_ERROR;
             s->adler = (uint32_t)adler32(s->adler, src, (uInt)take);
         } else {
             if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
@@ -478,7 +487,8 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
             if (!buf_put(&w, s->dict.p, s->dict.len) || !buf_put(&w, src, take)) { free(w.p); return Z_MEM_ERROR; }
             const uint64_t cap = zgpu_deflate_bound(w.len, CHUNK);
             if (!buf_reserve(&s->out, cap)) { free(w.p); return Z_MEM_ERROR; }
-            zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, 0};
+            zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, s->dprime};
+            s->dprime = 0;
             zgpu_deflate_result r;
             zgpu_engine *e = engine_checkout();
             zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
@@ -497,7 +507,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
         src += take; n -= take;
     }
     if (s->level == 0) {
-        if (!stored_chunks(&s->out, src, n, final)) return Z_MEM_ERROR;
+        if (!stored_chunks(&s->out, src, n, final, &s->dprime)) return Z_MEM_ERROR;
         for (size_t o = 0; o < n; o += 0x40000000u) {
             size_t m = n - o < 0x40000000u ? n - o : 0x40000000u;
             if (s->wrap == 2) s->crc = (uint32_t)crc32(s->crc, src + o, (uInt)m); else s->adler = (uint32_t)adler32(s->adler, src + o, (uInt)m);
@@ -521,10 +531,11 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
             const size_t b0 = c0 * CHUNK, b1 = d + 1 == used ? n : c1 * CHUNK;
             struct multi_job *j = &job[d];
             j->e = g_multi[d]; j->lock = &g_multi_lock[d]; j->src = src + b0; j->n = b1 - b0;
-            j->p = (zgpu_deflate_params){s->level, CHUNK, ((final && d + 1 == used) ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
+            j->p = (zgpu_deflate_params){s->level, CHUNK, ((final && d + 1 == used) ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, d == 0 ? s->dprime : 0u};
             j->cap = zgpu_deflate_bound(j->n, CHUNK); j->dst = s->out.p + s->out.len + at; at += j->cap;
             j->tuned = s->tuned; memcpy(j->tune, s->tune, sizeof j->tune); j->rc = ZGPU_ERRNO;
         }
+        s->dprime = 0;
         int started = 0;
         for (; started < used; started++) if (pthread_create(&th[started], NULL, multi_worker, &job[started]) != 0) break;
         for (int d = 0; d < started; d++) pthread_join(th[d], NULL);
@@ -544,7 +555,8 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
         return Z_OK;
     }
     if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
-    zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, 0};
+    zgpu_deflate_params p = {s->level, CHUNK, (final ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, s->dprime};
+    s->dprime = 0;
     zgpu_deflate_result r;
     e = engine_checkout();
     zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
