@@ -156,13 +156,22 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     eng = zlib_amd.Engine(local)
-    comm = None
+    comm, comm_note = None, None
     if world > 1:
         def exchange_id(b):  # rank 0's RCCL id to everybody, over the group that exists for the barrier
             t = torch.tensor(list(b), dtype=torch.uint8, device=dev)
             dist.broadcast(t, 0)
             return bytes(t.cpu().tolist())
-        comm = gpu.Comm(local, world, rank, exchange_id)
+        comm_note = "zgpu_deflate_gather (RCCL inside the C library)"
+        try:
+            comm = gpu.Comm(local, world, rank, exchange_id)
+        except Exception as ex:  # the ranks agree below on what carries the gather
+            comm, comm_note = None, "torch.distributed gather (the C library's communicator could not be made: %s)" % ex
+        agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0 and comm is not None:
+            comm.close()
+            comm, comm_note = None, "torch.distributed gather (another rank could not make the C library's communicator)"
     kind = 0 if a.workload == "silesia-mix" else 1
     seed = 0x5EED5117 if kind == 0 else 0x10C7E47
     nchunks = int(a.gib * 2**30) // 65536
@@ -188,6 +197,13 @@ def main():
                                  lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
         state["res"] = res
         nonlocal gather_buf
+        if comm is None:  # zlib_amd/shard.py: the same exchange over the process group
+            body = dst[: res.out_bytes]
+            _, total = shard.gather_stream(body, res.adler32, nbytes, a.level, out=gather_buf if rank == 0 else None)
+            if rank == 0 and (gather_buf is None or gather_buf.numel() < total):
+                gather_buf = torch.empty(total + (total >> 4), dtype=torch.uint8, device=dev)  # (the next step reuses it)
+            state["gathered"] = total
+            return
         # the C library's RCCL gather (include/zamd_gpu.h zgpu_deflate_gather): sizes first, so that rank 0's buffer is exactly as large as the stream
         table, total = comm.sizes(res.out_bytes, res.adler32, nbytes, stream=stream)
         if rank == 0 and (gather_buf is None or gather_buf.numel() < total):
@@ -284,7 +300,7 @@ def main():
             "config": {"workload": "%s %.2f GiB per GPU, 64 KiB independent chunks, level %d, bit-exact vs zlib 1.2.3" % (
                 a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
-                "gathered_bytes": int(state.get("gathered", res.out_bytes)),
+                "gathered_bytes": int(state.get("gathered", res.out_bytes)), "gather": comm_note,
                 "chunks_checked_against_reference_hashes": (check_sampled_chunks(torch, dst, offs, nchunks, rank * nchunks, a.level, a.workload)
                                                             if a.op == "deflate" else None)},
             "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -45,7 +46,10 @@ bool rccl_open()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.h) return true;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); // PyTorch's copy, if this process has it
+    const char *named = getenv("ZAMD_RCCL_LIB"); // another build of RCCL (or the test double of tests/tools/fake_rccl.cpp, for ranks that share one GPU)
+    void *h = (named && named[0]) ? dlopen(named, RTLD_NOW) : nullptr;
+    if (named && named[0] && !h) return false;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); // PyTorch's copy, if this process has it
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
     if (!h) h = dlopen("librccl.so", RTLD_NOW);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW);

@@ -300,11 +300,12 @@ class Comm:
         self.L = load_library()
         self.world, self.rank = world, rank
         ident = np.zeros(128, dtype=np.uint8)
-        if rank == 0:
-            rc = self.L.zgpu_comm_unique_id(ident.ctypes.data)
-            if rc != 0:
-                raise EngineError(rc, self.L.zgpu_comm_error().decode())
-        ident = np.frombuffer(exchange_id(ident.tobytes()), dtype=np.uint8).copy()
+        rc0 = self.L.zgpu_comm_unique_id(ident.ctypes.data) if rank == 0 else 0
+        if rc0 != 0:
+            ident[:] = 0
+        ident = np.frombuffer(exchange_id(ident.tobytes()), dtype=np.uint8).copy()  # (also when rank 0 has no id: the others must not wait for it)
+        if rc0 != 0 or not ident.any():
+            raise EngineError(rc0 or -2, self.L.zgpu_comm_error().decode() if rank == 0 else "rank 0 could not make an RCCL id")
         h = C.c_void_p()
         rc = self.L.zgpu_comm_create(device, world, rank, ident.ctypes.data, C.byref(h))
         if rc != 0:
