@@ -150,16 +150,25 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
+    # ZAMD_BENCH_SHARE_GPU=1: a REHEARSAL of the N > 1 flow on a box with one GPU (every rank on GPU 0, gloo for the process group, and
+    # ZAMD_RCCL_LIB naming the test double of tests/tools/fake_rccl.cpp).  Its JSON line says so; it is no measurement.
+    share = os.environ.get("ZAMD_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if share else dev  # where the few control tensors of the process group live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     eng = zlib_amd.Engine(local)
     comm, comm_note = None, None
     if world > 1:
         def exchange_id(b):  # rank 0's RCCL id to everybody, over the group that exists for the barrier
-            t = torch.tensor(list(b), dtype=torch.uint8, device=dev)
+            t = torch.tensor(list(b), dtype=torch.uint8, device=cdev)
             dist.broadcast(t, 0)
             return bytes(t.cpu().tolist())
         comm_note = "zgpu_deflate_gather (RCCL inside the C library)"
@@ -167,7 +176,7 @@ def main():
             comm = gpu.Comm(local, world, rank, exchange_id)
         except Exception as ex:  # the ranks agree below on what carries the gather
             comm, comm_note = None, "torch.distributed gather (the C library's communicator could not be made: %s)" % ex
-        agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         if int(agreed.item()) == 0 and comm is not None:
             comm.close()
@@ -248,7 +257,7 @@ def main():
 
     dt, prof = timed(step, a.steps, a.warmup)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -301,6 +310,7 @@ def main():
                 a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
                 "gathered_bytes": int(state.get("gathered", res.out_bytes)), "gather": comm_note,
+                **({"rehearsal": "ZAMD_BENCH_SHARE_GPU: all ranks on one GPU, no measurement"} if share else {}),
                 "chunks_checked_against_reference_hashes": (check_sampled_chunks(torch, dst, offs, nchunks, rank * nchunks, a.level, a.workload)
                                                             if a.op == "deflate" else None)},
             "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),

@@ -52,3 +52,22 @@ def test_sharded_stream_is_the_single_engine_stream(fake_rccl, tmp_path, world, 
     assert z == whole
     assert zlib.decompress(z) == data.tobytes()
     assert int(open(out_file + ".adler").read()) == zlib.adler32(data.tobytes())
+
+
+def test_bench_flow_with_two_ranks_on_one_gpu(fake_rccl):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on one GPU: ZAMD_BENCH_SHARE_GPU puts both
+    ranks on GPU 0 with a gloo group, the C library's gather runs over the test double.  The line must carry the whole job (both ranks' input) and the
+    gathered stream's length; the value is no measurement."""
+    import json
+    env = dict(os.environ, ZAMD_RCCL_LIB=fake_rccl, ZAMD_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gib", "0.125"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    cfg = j["config"]
+    assert cfg["gather"].startswith("zgpu_deflate_gather") and "rehearsal" in cfg
+    assert cfg["gathered_bytes"] > cfg["stream_bytes"] + 6 and cfg["chunks_checked_against_reference_hashes"] > 0

@@ -51,19 +51,21 @@ ncclResult_t run(const Op &o)
 {
     Comm *c = o.c;
     if (hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
-    if (o.n > kSlotCap) return ncclInvalidArgument;
-    if (o.send) {
-        Slot &s = c->m->slot[c->rank];
-        if (!wait_until(&s.seq_r, s.seq_w)) return ncclSystemError; // the slot is free again
-        if (hipMemcpy(c->data + (size_t)c->rank * kSlotCap, o.buf, o.n, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-        s.size = o.n; s.dst = (uint64_t)o.peer;
-        __atomic_add_fetch(&s.seq_w, 1, __ATOMIC_ACQ_REL);
-    } else {
-        Slot &s = c->m->slot[o.peer];
-        if (!wait_until(&s.seq_w, s.seq_r + 1)) return ncclSystemError;
-        if (s.size != o.n || s.dst != (uint64_t)c->rank) return ncclInvalidUsage; // a send and its receive must agree in size and peer
-        if (hipMemcpy(o.buf, c->data + (size_t)o.peer * kSlotCap, o.n, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-        __atomic_add_fetch(&s.seq_r, 1, __ATOMIC_ACQ_REL);
+    for (size_t at = 0; at == 0 || at < o.n; at += kSlotCap) { // (a message longer than a slot goes piece by piece, both sides cut it alike)
+        const size_t piece = o.n - at < kSlotCap ? o.n - at : kSlotCap;
+        if (o.send) {
+            Slot &s = c->m->slot[c->rank];
+            if (!wait_until(&s.seq_r, s.seq_w)) return ncclSystemError; // the slot is free again
+            if (hipMemcpy(c->data + (size_t)c->rank * kSlotCap, static_cast<uint8_t *>(o.buf) + at, piece, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+            s.size = piece; s.dst = (uint64_t)o.peer;
+            __atomic_add_fetch(&s.seq_w, 1, __ATOMIC_ACQ_REL);
+        } else {
+            Slot &s = c->m->slot[o.peer];
+            if (!wait_until(&s.seq_w, s.seq_r + 1)) return ncclSystemError;
+            if (s.size != piece || s.dst != (uint64_t)c->rank) return ncclInvalidUsage; // a send and its receive must agree in size and peer
+            if (hipMemcpy(static_cast<uint8_t *>(o.buf) + at, c->data + (size_t)o.peer * kSlotCap, piece, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+            __atomic_add_fetch(&s.seq_r, 1, __ATOMIC_ACQ_REL);
+        }
     }
     return ncclSuccess;
 }
