@@ -121,6 +121,14 @@ void zgpu_engine_destroy(zgpu_engine *e);
 const char *zgpu_engine_error(const zgpu_engine *e);
 const char *zgpu_version(void);
 
+/* deflateInit2's geometry (qcsrc/deflate.c:222-297) for the calls that follow: windowBits 9..15 (the window is 2^windowBits bytes, matches reach
+ * 2^windowBits - 262 back, the window slides every 2^windowBits bytes) and memLevel 1..9 (hash of memLevel + 7 bits, a block is cut after
+ * 2^(memLevel+6) - 1 tokens).  15 / 8 is the default and what every kernel is built for; any other geometry is served by the lane-per-chunk loop
+ * (ZGPU_LZ_SERIAL) and the same block-construction kernel, bit-exact with the reference's chunk function under that deflateInit2.  Output
+ * capacity: zgpu_deflate_bound_geometry. */
+int zgpu_deflate_set_geometry(zgpu_engine *e, int window_bits, int mem_level);
+uint64_t zgpu_deflate_bound_geometry(uint64_t in_bytes, uint32_t chunk_size, int window_bits, int mem_level);
+
 /* deflateTune (qcsrc/deflate.c:453-470): while `on`, the deflate calls of this engine use these four parameters of the match
  * search instead of the level's row of configuration_table (deflate.c:137-149); the level keeps its compress function
  * (deflate_fast for 1..3, deflate_slow for 4..9). */

@@ -82,3 +82,14 @@ HELLO = b"hello, hello!\x00"
 
 def hello_1mib() -> bytes:
     return (b"hello, hello! " * (CHUNK * 16 // 14 + 1))[: CHUNK * 16]
+
+
+def nomatch(n: int) -> bytes:
+    """n <= 32768 bytes in which no three-byte string occurs twice (pairs of a 7-bit digit and a 7-bit digit with the top bit set): every token is a
+    literal, so the token count is the byte count -- the input for "the buffer fills exactly at ..." cases (tests/golden/fullblock_kat.json)."""
+    b = bytearray()
+    i = 0
+    while len(b) < n:
+        b += bytes([i & 127, 0x80 | ((i >> 7) & 127)])
+        i += 1
+    return bytes(b[:n])

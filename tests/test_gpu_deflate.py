@@ -153,3 +153,25 @@ def test_corpus_device_generator_matches_host(eng):
         eng.corpus_fill_device(kind, CP.default_seed(kind), first, n, buf.data_ptr())
         torch.cuda.synchronize()
         assert buf.cpu().numpy().tobytes() == CP.chunks(kind, first, n).tobytes()
+
+
+def test_token_count_that_fills_a_block_exactly(eng):
+    """tests/golden/fullblock_kat.json (the compiled reference): chunks with 16383 * k tokens.  deflate_fast cuts the full block and the chunk's end adds
+    an empty one; deflate_slow's trailing literal is tallied behind the loop (deflate.c:1660-1665) and the full block is the last one.  Every
+    implementation, both endings, one launch per level and implementation."""
+    import json
+    import os
+    from oracle import gen_golden_fullblock as G
+    from zlib_amd import gpu
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullblock_kat.json")))
+    ins = dict(G.inputs())
+    bad = []
+    for level in sorted({c["level"] for c in kat}):
+        cs = [c for c in kat if c["level"] == level]
+        for impl in impls(level):
+            for last in (0, 1):
+                segs = eng.deflate_segments_host([ins[c["name"]] for c in cs], level, flags=gpu.F_FINAL if last else 0, lz_impl=impl)
+                for c, z in zip(cs, segs):
+                    if (len(z), h16(z)) != (c["len"][last], c["sha"][last]):
+                        bad.append((c["name"], level, impl, last, len(z), c["len"][last]))
+    assert not bad, (len(bad), bad[:16])

@@ -1,6 +1,7 @@
 """The CPU restatement (oracle/) against the committed golden vectors, which were produced by the real
 reference (oracle/gen_golden.py -> tests/golden/).  Runs anywhere, no GPU, no /root/reference."""
 import hashlib
+import os
 
 import pytest
 
@@ -98,3 +99,16 @@ def test_roundtrip_every_level():
         z = O.deflate_stream(data, lvl)
         rc, out, used, msg = O.inflate_zlib(z, len(data))
         assert rc == 1 and out == data and used == len(z), lvl
+
+
+def test_oracle_on_chunks_whose_token_count_fills_the_buffer_exactly():
+    """tests/golden/fullblock_kat.json (the compiled reference, oracle/gen_golden_fullblock.py): deflate_slow's trailing literal does not cut a block."""
+    import hashlib
+    import json
+    from oracle import gen_golden_fullblock as G
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullblock_kat.json")))
+    ins = dict(G.inputs())
+    for c in kat:
+        for last in (0, 1):
+            z = O.deflate_chunk(ins[c["name"]], c["level"], bool(last))
+            assert (len(z), hashlib.sha256(z).hexdigest()[:16]) == (c["len"][last], c["sha"][last]), (c["name"], c["level"], last)

@@ -16,12 +16,18 @@ constexpr uint32_t kMaxDist = kWSize - kMinLookahead; // 32506
 constexpr uint32_t kTooFar = 4096;
 constexpr uint32_t kChunkMax = 65536;
 constexpr uint32_t kBlockTokens = 16383;       // lit_bufsize-1: a block is cut after this many tokens
-constexpr uint32_t kMaxBlocks = 6;             // ceil(65536/16383) + a possible empty final block
+constexpr uint32_t kGeoTableEntries = 65536 + 32768; // u16 entries per chunk of the lane-per-chunk loop's head[] + prev[] at memLevel 9 / windowBits 15
+constexpr uint32_t kGeoNostoreWords = 18;     // memLevel 1: 127 tokens a block, up to 517 blocks in a chunk
+constexpr uint32_t kGeoSlotStride = 65536 + 8192 + 1024 + 64 + 5 * 32 * kGeoNostoreWords + 448; // deflateBound's arithmetic (deflate.c:513-515) for a chunk whose blocks may not be stored, + a header per block
+constexpr uint32_t kMaxBlocks = 6;
+// ChunkMeta::nostore bit 31: deflate_slow tallies the last byte's literal behind its loop without looking at "buffer full" (deflate.c:1660-1665), so when that
+// literal is the token that fills a block, the block is flushed as the chunk's LAST one -- there is no empty block behind it
+constexpr uint32_t kFullFinalBlock = 1u << 31;             // ceil(65536/16383) + a possible empty final block
 constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCodes + 1, kMaxBits = 15, kMaxBLBits = 7;
 constexpr int kEndBlock = 256;
 constexpr uint32_t kSlotStride = 65536 + 256;  // per-chunk output slot (worst case: 5 stored blocks + marker = +30)
 
-struct LevelCfg { uint32_t good, lazy, nice, chain, slow, strategy; }; // strategy: Z_DEFAULT_STRATEGY 0 .. Z_FIXED 4 (h/zlib.h:176-181)
+struct LevelCfg { uint32_t good, lazy, nice, chain, slow, strategy; uint32_t w_bits, hash_bits; }; // w_bits, hash_bits: 0 = the default geometry (15, 15); else deflateInit2's windowBits and memLevel + 7 // strategy: Z_DEFAULT_STRATEGY 0 .. Z_FIXED 4 (h/zlib.h:176-181)
 constexpr uint32_t kFiltered = 1, kHuffmanOnly = 2, kRle = 3, kFixed = 4;
 inline LevelCfg level_cfg(int level)
 {
@@ -34,7 +40,7 @@ inline LevelCfg level_cfg(int level)
 // Per-chunk record passed between the LZ77 stage, the Huffman stage and the stitcher.
 struct ChunkMeta {
     uint32_t ntok;        // tokens produced by the LZ77 stage
-    uint32_t nostore;     // bit b set: block b may not be emitted stored (reference: buf == NULL after the slide)
+    uint32_t nostore;     // bit b set: block b may not be emitted stored (reference: buf == NULL after the slide); kFullFinalBlock: see there
     uint32_t out_bytes;   // compressed bytes in the chunk's slot
     uint32_t data_type;   // Z_BINARY 0 / Z_TEXT 1 / Z_UNKNOWN 2 from the first non-empty block
     uint32_t adler_a, adler_b; // Adler-32 halves of the chunk bytes, as if started from 1
@@ -56,6 +62,10 @@ struct ChunkGeom {
     uint32_t pos0_mode;      // 0 none, 1 chunks other than global chunk 0, 2 all chunks are position-0 matchable
     uint32_t skip0;          // preset dictionary: global chunk 0 starts with this many bytes that are window content, not data
     uint32_t prime;          // deflatePrime: (nbits << 16) | value, the bits global chunk 0 starts behind
+    // deflateInit2's geometry (deflate.c:222-297) when it is not the default windowBits 15 / memLevel 8 (the lane-per-chunk loop serves it):
+    uint32_t block_tokens;   // lit_bufsize - 1: a block is cut after this many tokens (kBlockTokens by default)
+    uint32_t slot_stride;    // bytes between the chunks' output slots (kSlotStride by default)
+    const uint32_t *nostore_bits; // nullptr: ChunkMeta::nostore has a bit per block; else kGeoNostoreWords words per chunk (a chunk may have 517 blocks)
 };
 __device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, uint32_t &n)
 {

@@ -14,7 +14,7 @@ namespace zgpu {
 struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 // kernels (other translation units)
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits);
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
@@ -55,6 +55,8 @@ struct zgpu_engine {
     uint32_t tables_cap = 0;
     void *par_ws = nullptr;      // parallel LZ only
     int tuned = 0; uint32_t tune[4] = {0, 0, 0, 0}; // zgpu_deflate_set_tuning: good, lazy, nice, chain instead of the level's
+    int geo_w = 15, geo_m = 8;   // zgpu_deflate_set_geometry: deflateInit2's windowBits and memLevel
+    uint8_t *geo_slots = nullptr; uint16_t *geo_tables = nullptr; uint32_t *geo_nostore = nullptr; uint32_t geo_cap = 0; // the workspace of a non-default geometry
     int exact_sort = 0;          // sticky: the fast sort's self-check failed once on this engine (zgpu_lz_sorted.hip, pass V)
     uint32_t par_cap = 0;
     uint64_t *offsets = nullptr; // nchunks+1 segment offsets of the current call
@@ -133,9 +135,16 @@ static uint32_t env_u32(const char *name, uint32_t dflt)
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64_t nchunks_total)
+static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64_t nchunks_total, bool geo = false)
 {
     int rc;
+    if (geo && batch > e->geo_cap) { // wider slots (blocks that may not be stored grow), head[] of up to 65536 entries, a flag word array per chunk
+        hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); e->geo_slots = nullptr; e->geo_tables = nullptr; e->geo_nostore = nullptr; e->geo_cap = 0;
+        if ((rc = dev_alloc(e, &e->geo_slots, (size_t)batch * kGeoSlotStride))) return rc;
+        if ((rc = dev_alloc(e, &e->geo_tables, (size_t)batch * kGeoTableEntries))) return rc;
+        if ((rc = dev_alloc(e, &e->geo_nostore, (size_t)batch * kGeoNostoreWords))) return rc;
+        e->geo_cap = batch;
+    }
     if (batch > e->batch_cap) {
         hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); e->tokens = nullptr; e->meta = nullptr; e->slots = nullptr; e->batch_cap = 0;
         if ((rc = dev_alloc(e, &e->tokens, (size_t)batch * kChunkMax))) return rc;
@@ -143,7 +152,7 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
         if ((rc = dev_alloc(e, &e->slots, (size_t)batch * kSlotStride))) return rc;
         e->batch_cap = batch;
     }
-    if (serial && batch > e->tables_cap) {
+    if (serial && !geo && batch > e->tables_cap) {
         hipFree(e->tables); e->tables = nullptr; e->tables_cap = 0;
         if ((rc = dev_alloc(e, &e->tables, (size_t)batch * (kHashSize + kWSize)))) return rc;
         e->tables_cap = batch;
@@ -197,7 +206,13 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // or the nearest one only (and then only at distance 1, see match3_kernel)
     if (cfg.slow && cfg.strategy == kHuffmanOnly) cfg.chain = 0;
     if (cfg.slow && cfg.strategy == kRle) cfg.chain = 1;
+    // deflateInit2's geometry (zgpu_deflate_set_geometry): anything but windowBits 15 / memLevel 8 goes to the lane-per-chunk loop, the one
+    // implementation whose window size, hash width and block length are run-time values
+    const bool geo = e->geo_w != 15 || e->geo_m != 8;
+    if (geo) { cfg.w_bits = (uint32_t)e->geo_w; cfg.hash_bits = (uint32_t)e->geo_m + 7; }
+    const uint32_t max_dist = (geo ? 1u << e->geo_w : kWSize) - kMinLookahead;
     int impl = p->lz_impl;
+    if (geo && impl != ZGPU_LZ_AUTO && impl != ZGPU_LZ_SERIAL) return fail(e, ZGPU_STREAM_ERROR, "a non-default windowBits / memLevel is served by ZGPU_LZ_SERIAL only");
     // the parse-driven search plays deflate_slow's own game; the two strategies that are chain budgets of the all-position search
     // (Z_HUFFMAN_ONLY, Z_RLE) stay with that search
     const bool walk_ok = cfg.strategy != kHuffmanOnly && cfg.strategy != kRle;
@@ -226,10 +241,11 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (impl == ZGPU_LZ_PARALLEL && p->strategy != 0) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_PARALLEL serves the default strategy only");
     if (impl == ZGPU_LZ_WALK && !walk_ok) return fail(e, ZGPU_STREAM_ERROR, "ZGPU_LZ_WALK does not serve Z_HUFFMAN_ONLY / Z_RLE");
     if (skip0) { // a preset dictionary in front of the one chunk: the lane-per-chunk loop is the implementation that starts mid-window
-        if (d_seg || in_bytes > kChunkMax || skip0 < kMinMatch || skip0 > kMaxDist || skip0 > in_bytes || (p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP | ZGPU_F_POS0 | ZGPU_F_POS0_ALL)))
+        if (d_seg || in_bytes > kChunkMax || skip0 < kMinMatch || skip0 > max_dist || skip0 > in_bytes || (p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP | ZGPU_F_POS0 | ZGPU_F_POS0_ALL)))
             return fail(e, ZGPU_STREAM_ERROR, "dictionary chunk: 3..32506 dictionary bytes + data <= 65536, no wrapper");
         impl = ZGPU_LZ_SERIAL;
     }
+    if (geo) impl = ZGPU_LZ_SERIAL;
     const bool serial = impl == ZGPU_LZ_SERIAL;
     if (d_seg && ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
@@ -244,7 +260,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
+        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
@@ -254,7 +270,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         }
     }
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
-    int rc = ensure_deflate_ws(e, batch, serial, nchunks);
+    int rc = ensure_deflate_ws(e, batch, serial, nchunks, geo);
     if (rc) return rc;
     const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP, gz = p->flags & ZGPU_F_GZIP_WRAP;
     const uint32_t head_bytes = wrap ? 2 : gz ? 10 : 0, tail_bytes = wrap ? 4 : gz ? 8 : 0;
@@ -264,6 +280,10 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     g.all_final = (d_seg && (p->flags & ZGPU_F_FINAL)) ? 1u : 0u;
     g.pos0_mode = (p->flags & ZGPU_F_POS0_ALL) ? 2u : (p->flags & ZGPU_F_POS0) ? 1u : 0u;
     g.skip0 = skip0;
+    g.block_tokens = geo ? (1u << (e->geo_m + 6)) - 1u : kBlockTokens;
+    g.slot_stride = geo ? kGeoSlotStride : kSlotStride;
+    g.nostore_bits = geo ? e->geo_nostore : nullptr;
+    uint8_t *const slots = geo ? e->geo_slots : e->slots;
     g.prime = (p->prime >> 16) ? ((p->prime & 0xffff0000u) | (p->prime & ((1u << (p->prime >> 16)) - 1u))) : 0u;
     const uint64_t body_cap = tail_bytes ? (out_cap >= head_bytes + tail_bytes ? out_cap - tail_bytes : 0) : out_cap;
 
@@ -333,8 +353,13 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         bool adler_done = false;
         if (serial) {
             StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
-            ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
-            launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st);
+            if (geo) {
+                ZGPU_HIP_CHECK(hipMemset2DAsync(e->geo_tables, (size_t)kGeoTableEntries * 2, 0, (size_t)2 << cfg.hash_bits, nb, st)); // head[] only
+                launch_lz_serial(g, cfg, e->geo_tables, e->tokens, e->meta, st, e->geo_nostore);
+            } else {
+                ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
+                launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr);
+            }
         } else {
             if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN)
                 adler_done = launch_lz_sorted(g, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, impl == ZGPU_LZ_WALK ? 1 : impl == ZGPU_LZ_FAST ? 2 : impl == ZGPU_LZ_FASTWIN ? 3 : 0);
@@ -342,14 +367,14 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
-            launch_huffman(g, e->tokens, e->meta, e->slots, st, cfg.strategy == kFixed);
+            launch_huffman(g, e->tokens, e->meta, slots, st, cfg.strategy == kFixed);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_STITCH);
             if (!adler_done) launch_adler(g, e->meta, st); // (the sort of the default path has computed it on the way)
             if (gz || (p->flags & ZGPU_F_CRC32)) launch_crc(g, e->meta, st);
             launch_scan(e->meta, nb, c0, e->offsets, e->run, body_cap, st, gz || (p->flags & ZGPU_F_CRC32));
-            launch_stitch(e->slots, e->meta, e->offsets, c0, nb, d_out, body_cap, kSlotStride, st);
+            launch_stitch(slots, e->meta, e->offsets, c0, nb, d_out, body_cap, g.slot_stride, st);
         }
         if (home) {
             hipError_t he = hipMemcpyAsync(&e->pin_tot[nbatch], e->run, sizeof(uint64_t), hipMemcpyDeviceToHost, st); // RunState::out_total
@@ -452,7 +477,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     if (!e) return;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
-    hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
+    hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
@@ -471,6 +496,25 @@ uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size)
     if (chunk_size == 0 || chunk_size > kChunkMax) chunk_size = kChunkMax;
     uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1;
     return in_bytes + nchunks * 40 + 16; // <= 6 block headers of 5 bytes + 5-byte marker per chunk, + zlib framing
+}
+
+// The same for a stream made with deflateInit2(windowBits, memLevel): blocks of as few as 127 tokens (a header each), and blocks that may not be
+// stored because their start has left a small window (deflateBound's arithmetic, deflate.c:513-515, covers those).
+uint64_t zgpu_deflate_bound_geometry(uint64_t in_bytes, uint32_t chunk_size, int window_bits, int mem_level)
+{
+    if (window_bits == 15 && mem_level == 8) return zgpu_deflate_bound(in_bytes, chunk_size);
+    if (chunk_size == 0 || chunk_size > kChunkMax) chunk_size = kChunkMax;
+    if (mem_level < 1 || mem_level > 9) mem_level = 1;
+    const uint64_t nchunks = in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1, blocks = chunk_size / ((1u << (mem_level + 6)) - 1u) + 2;
+    return in_bytes + ((in_bytes + 7) >> 3) + ((in_bytes + 63) >> 6) + nchunks * (5 * blocks + 64) + 16;
+}
+
+int zgpu_deflate_set_geometry(zgpu_engine *e, int window_bits, int mem_level)
+{
+    if (!e) return ZGPU_STREAM_ERROR;
+    if (window_bits < 9 || window_bits > 15 || mem_level < 1 || mem_level > 9) return fail(e, ZGPU_STREAM_ERROR, "windowBits 9..15, memLevel 1..9");
+    e->geo_w = window_bits; e->geo_m = mem_level;
+    return ZGPU_OK;
 }
 
 int zgpu_deflate_set_tuning(zgpu_engine *e, int on, uint32_t good_length, uint32_t max_lazy, uint32_t nice_length, uint32_t max_chain)
@@ -493,7 +537,7 @@ int zgpu_deflate_dict_chunk_host(zgpu_engine *e, const void *window, uint32_t wi
 {
     if (!e || !p || !res || !window || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
-    const uint64_t bound = zgpu_deflate_bound(window_bytes, kChunkMax);
+    const uint64_t bound = zgpu_deflate_bound_geometry(window_bytes, kChunkMax, e ? e->geo_w : 15, e ? e->geo_m : 8);
     int rc = ensure_stage(e, window_bytes, bound);
     if (rc) return rc;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, window, window_bytes, hipMemcpyHostToDevice, e->stream));
@@ -513,7 +557,7 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
     if (!e || !p || !res || (!in && in_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
     const uint32_t chunk_size = p->chunk_size ? p->chunk_size : kChunkMax;
-    const uint64_t bound = zgpu_deflate_bound(in_bytes, chunk_size);
+    const uint64_t bound = zgpu_deflate_bound_geometry(in_bytes, chunk_size, e ? e->geo_w : 15, e ? e->geo_m : 8);
     int rc = ensure_stage(e, in_bytes, bound);
     if (rc) return rc;
     // (the copy stream must not run ahead of the previous call's kernels, which may still read the staging buffer: it starts behind them)
@@ -549,7 +593,9 @@ int zgpu_deflate_segments_host(zgpu_engine *e, const void *in, const uint64_t *s
     const uint64_t in_bytes = seg_offsets[nseg];
     for (uint64_t k = 0; k < nseg; k++)
         if (seg_offsets[k + 1] < seg_offsets[k] || seg_offsets[k + 1] - seg_offsets[k] > kChunkMax) return fail(e, ZGPU_STREAM_ERROR, "segment longer than 65536 bytes");
-    const uint64_t bound = in_bytes + nseg * 40 + 16;
+    // (every segment may be a chunk of its own: with a non-default geometry each gets the allowance of a full chunk)
+    const uint64_t bound = (e->geo_w != 15 || e->geo_m != 8) ? in_bytes + zgpu_deflate_bound_geometry(nseg * (uint64_t)kChunkMax, kChunkMax, e->geo_w, e->geo_m) - nseg * (uint64_t)kChunkMax + ((nseg * (uint64_t)kChunkMax) >> 3)
+                                                             : in_bytes + nseg * 40 + 16;
     int rc = ensure_stage(e, in_bytes + (nseg + 1) * sizeof(uint64_t) + 64, bound);
     if (rc) return rc;
     const uint64_t tab_off = (in_bytes + 63) & ~63ull; // segment table staged behind the data

@@ -530,16 +530,17 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
     chunk_span(g, c, lo, nbytes);
     const uint8_t *src = g.in + lo;
     const uint32_t *tok = tokens + (size_t)c * kChunkMax;
-    uint32_t *out = reinterpret_cast<uint32_t *>(slots + (size_t)c * kSlotStride);
+    uint32_t *out = reinterpret_cast<uint32_t *>(slots + (size_t)c * g.slot_stride);
     const uint32_t ntok = meta[c].ntok, nostore = meta[c].nostore;
     const bool final_chunk_here = chunk_is_final(g, c);
-    const uint32_t nblocks = ntok / kBlockTokens + 1;
+    const uint32_t btok = g.block_tokens, nblocks = ntok / btok + ((nostore & kFullFinalBlock) ? 0u : 1u); // (a last block filled by deflate_slow's trailing literal has no empty block behind it)
+    const uint32_t *nostore_bits = g.nostore_bits ? g.nostore_bits + (size_t)c * kGeoNostoreWords : nullptr;
     uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
     if (tid == 0) { const uint32_t pr = chunk_prime(g, c); sh_bitpos = pr >> 16; sh_carry = pr & 0xffffu; } // (deflatePrime: bi_valid and bi_buf as the first block finds them, deflate.c:411-412)
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
-        const uint32_t t0 = b * kBlockTokens, t1 = (b + 1 == nblocks) ? ntok : t0 + kBlockTokens, nt = t1 - t0;
+        const uint32_t t0 = b * btok, t1 = (b + 1 == nblocks) ? ntok : t0 + btok, nt = t1 - t0;
         const uint32_t eof = (final_chunk_here && b + 1 == nblocks) ? 1u : 0u;
         // ---- histogram (init_block + tally) ----
         for (uint32_t i = tid; i < kLCodes + kDCodes + 2; i += kThreads) hist[i] = 0;
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
                 uint32_t opt_lenb = (opt_len + 3 + 7) >> 3, static_lenb = (static_len + 3 + 7) >> 3;
                 if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
                 uint32_t btype;
-                if (stored_len + 4 <= opt_lenb && !((nostore >> b) & 1)) btype = 0;
+                if (stored_len + 4 <= opt_lenb && !(nostore_bits ? (nostore_bits[b >> 5] >> (b & 31u)) & 1u : (nostore >> b) & 1u)) btype = 0;
                 else if (fixed_trees || static_lenb == opt_lenb) btype = 1; // Z_FIXED: trees.c:986
                 else btype = 2;
                 sh_btype = btype;

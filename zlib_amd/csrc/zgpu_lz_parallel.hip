@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(64) parse_kernel(ChunkGeom g, LevelCfg cfg, co
             nblk++; blk_tok0 = ntok; block_start = p;
         }
     }
-    if (pending) tok[ntok++] = tok_lit(prev_byte);
+    if (pending) { tok[ntok++] = tok_lit(prev_byte); if (ntok - blk_tok0 == kBlockTokens) nostore |= kFullFinalBlock; } // (deflate.c:1660-1665: no cut behind this literal)
     if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk;
     meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n;
 }

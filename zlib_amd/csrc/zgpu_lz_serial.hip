@@ -20,13 +20,24 @@ namespace zgpu {
 struct __attribute__((packed, aligned(1))) U32s { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U64s { uint64_t v; };
 
-struct SerialLz {
+// kGeo: deflateInit2's windowBits / memLevel are not the default (deflate.c:222-297): window size, hash width and shift and the tokens of a block
+// are run-time values, the window may slide many times in a chunk (the derived index covers that: `off` grows by a window each time), and the
+// "may not be stored" flags go to a bit array of their own (a chunk can have more than 32 blocks).
+template <bool kGeo>
+struct SerialLzT {
     const uint8_t *__restrict__ in;
     uint32_t n, base, off, start; // start: a preset dictionary occupies positions [0, start) (deflate.c:315-354)
     uint16_t *head, *prev;
     uint32_t *tok;
     uint32_t ntok, blk_tok0, nblk, nostore, block_start;
     LevelCfg cfg;
+    uint32_t g_wsize, g_hmask, g_hshift, g_btok; // (kGeo)
+    uint32_t *g_nostore;
+    __device__ uint32_t wsize() const { return kGeo ? g_wsize : kWSize; }
+    __device__ uint32_t wmask() const { return wsize() - 1u; }
+    __device__ uint32_t maxdist() const { return wsize() - kMinLookahead; }
+    __device__ uint32_t btok() const { return kGeo ? g_btok : kBlockTokens; }
+    __device__ uint32_t hash(uint32_t b0, uint32_t b1, uint32_t b2) const { return kGeo ? ((b0 << (2 * g_hshift)) ^ (b1 << g_hshift) ^ b2) & g_hmask : hash3(b0, b1, b2); } // UPDATE_HASH three times (deflate.c:181)
 
     __device__ int widx(uint32_t p) const { return (int)(p + base) - (int)off; }
     // derived window index of a table entry; <= 0 means NIL
@@ -37,29 +48,43 @@ struct SerialLz {
         // (every global load of this lane-per-chunk loop is a dependent round trip of several hundred ns even when it hits:
         // one unaligned dword instead of three byte loads, eight bytes per comparison step instead of one)
         uint32_t h;
-        if (p + 4 <= n) { const uint32_t v = reinterpret_cast<const U32s *>(in + p)->v; h = hash3(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u); }
-        else h = hash3(in[p], in[p + 1], in[p + 2]);
+        if (p + 4 <= n) { const uint32_t v = reinterpret_cast<const U32s *>(in + p)->v; h = hash(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u); }
+        else h = hash(in[p], in[p + 1], in[p + 2]);
         uint32_t old = head[h];
-        prev[(p + base) & kWMask] = (uint16_t)old;
+        prev[(p + base) & wmask()] = (uint16_t)old;
         head[h] = (uint16_t)(p + 1);
         return old;
     }
 
     // the slide test of fill_window (deflate.c:1293); called wherever the reference calls fill_window
-    __device__ void refill(uint32_t p) { if (widx(p) >= (int)(kWSize + kMaxDist)) off += kWSize; }
+    __device__ void refill(uint32_t p) { if (widx(p) >= (int)(wsize() + maxdist())) off += wsize(); }
+    // fill_window (deflate.c:1265-1350) with the whole chunk at hand: the slide if it is due, then as much input as the window has room for; returns
+    // the new count of buffered bytes
+    __device__ uint32_t fill(uint32_t p, uint32_t buffered)
+    {
+        if (!kGeo) { refill(p); return n; } // (one slide at most, late: everything that is left fits behind it)
+        do {
+            refill(p);
+            const uint32_t more = 2 * wsize() - (buffered - p) - (uint32_t)widx(p), left = n - buffered;
+            buffered += more < left ? more : left;
+        } while (buffered - p < kMinLookahead && buffered < n);
+        return buffered;
+    }
 
     __device__ void cut_block(uint32_t p_end)
     {
-        if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // buf == NULL, deflate.c:1365-1367
+        if ((int)(block_start + base) - (int)off < 0) { // buf == NULL, deflate.c:1365-1367: the block's first byte has left the window
+            if (kGeo) g_nostore[nblk >> 5] |= 1u << (nblk & 31u); else nostore |= 1u << nblk;
+        }
         nblk++; blk_tok0 = ntok; block_start = p_end;
     }
-    __device__ bool emit(uint32_t t) { tok[ntok++] = t; return ntok - blk_tok0 == kBlockTokens; }
+    __device__ bool emit(uint32_t t) { tok[ntok++] = t; return ntok - blk_tok0 == btok(); }
 
     // longest_match; e0 is the table entry of the first candidate.  Returns the match length and sets mstart.
     __device__ uint32_t longest(uint32_t p, uint32_t e0, uint32_t prev_length, uint32_t &mstart) const
     {
         uint32_t chain = cfg.chain, look = n - p, nice = cfg.nice, best = prev_length;
-        int w = widx(p), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+        int w = widx(p), limit = w > (int)maxdist() ? w - (int)maxdist() : 0;
         uint32_t cap = look < kMaxMatch ? look : kMaxMatch;
         if (prev_length >= cfg.good) chain >>= 2;
         if (nice > look) nice = look;
@@ -81,7 +106,7 @@ struct SerialLz {
             compared:
                 if (l > best) { mstart = q; best = l; if (l >= nice) break; }
             }
-            e = prev[(q + base) & kWMask];
+            e = prev[(q + base) & wmask()];
             if (e == 0 || entry_w(e) <= limit) break;
         } while (--chain != 0);
         return best <= look ? best : look;
@@ -99,23 +124,23 @@ struct SerialLz {
     }
 };
 
-template <bool kSlow>
-__device__ void lz_serial_chunk(SerialLz &s)
+template <bool kSlow, bool kGeo>
+__device__ void lz_serial_chunk(SerialLzT<kGeo> &s)
 {
-    const uint32_t n = s.n;
-    uint32_t room = 2 * kWSize - s.base, buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
+    const uint32_t n = s.n, maxd = s.maxdist();
+    uint32_t room = 2 * s.wsize() - s.base, buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
     uint32_t p = s.start, match_len = kMinMatch - 1, prev_len = 0, mstart = 0, prev_match = 0, hh = 0;
     bool pending = false;
     for (uint32_t q = 0; q + kMinMatch <= s.start; q++) s.insert(q); // all dictionary strings but the last two (deflate.c:345-351)
     for (;;) {
-        if (buffered - p < kMinLookahead) { s.refill(p); buffered = n; if (n == p) break; }
+        if (buffered - p < kMinLookahead) { buffered = s.fill(p, buffered); if (n == p) break; }
         uint32_t look = n - p;
         if (look >= kMinMatch) hh = s.insert(p);
         int hw = s.entry_w(hh), w = s.widx(p);
         bool cut = false;
         if (kSlow) {
             prev_len = match_len; prev_match = mstart; match_len = kMinMatch - 1;
-            if (hw > 0 && prev_len < s.cfg.lazy && (uint32_t)(w - hw) <= kMaxDist) {
+            if (hw > 0 && prev_len < s.cfg.lazy && (uint32_t)(w - hw) <= maxd) {
                 if (s.cfg.strategy != kHuffmanOnly && s.cfg.strategy != kRle) match_len = s.longest(p, hh, prev_len, mstart);
                 else if (s.cfg.strategy == kRle && w - hw == 1) match_len = s.fast_match(p, hh, mstart);
                 if (match_len <= 5 && (s.cfg.strategy == kFiltered || (match_len == kMinMatch && p - mstart > kTooFar))) match_len = kMinMatch - 1;
@@ -132,7 +157,7 @@ __device__ void lz_serial_chunk(SerialLz &s)
                 p++;
             } else { pending = true; p++; }
         } else {
-            if (hw > 0 && (uint32_t)(w - hw) <= kMaxDist) {
+            if (hw > 0 && (uint32_t)(w - hw) <= maxd) {
                 if (s.cfg.strategy != kHuffmanOnly && s.cfg.strategy != kRle) match_len = s.longest(p, hh, kMinMatch - 1, mstart);
                 else if (s.cfg.strategy == kRle && w - hw == 1) match_len = s.fast_match(p, hh, mstart);
             }
@@ -148,12 +173,16 @@ __device__ void lz_serial_chunk(SerialLz &s)
             if (cut) s.cut_block(p);
         }
     }
-    if (kSlow && pending) s.emit(tok_lit(s.in[p - 1]));
+    // the last byte's literal is tallied behind the loop and its "buffer full" is not looked at (deflate.c:1660-1665): when it is the token that fills
+    // the block, that block -- all its tokens -- is the final one, with no empty block behind it
+    if (kSlow && pending && s.emit(tok_lit(s.in[p - 1]))) s.nostore |= kFullFinalBlock;
     s.cut_block(p); // the final block (its emission happens in the Huffman stage)
 }
 
-// grid: one lane per chunk of the batch.  tables: per chunk 2 x 32768 u16 (head zeroed by the host side).
-__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes)
+// grid: one lane per chunk of the batch.  tables: per chunk head[] then prev[], u16 (head zeroed by the host side): 2 x 32768 entries, or
+// (kGeo) 2^hash_bits + 2^w_bits at a stride of kGeoTableEntries.
+template <bool kGeo>
+__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits)
 {
     // `lanes` chunks per wave: a wave's step takes as long as its slowest lane's memory access, and fewer lanes per wave
     // means more waves to overlap those waits (the vector work per step is next to nothing)
@@ -162,17 +191,25 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
     if (c >= g.nchunks) return;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
-    SerialLz s;
+    SerialLzT<kGeo> s;
     s.in = g.in + lo; s.n = n;
     s.base = chunk_base(g, c); s.off = 0; s.start = chunk_skip(g, c);
-    s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
+    if (kGeo) {
+        s.g_wsize = 1u << cfg.w_bits; s.g_hmask = (1u << cfg.hash_bits) - 1u; s.g_hshift = (cfg.hash_bits + kMinMatch - 1) / kMinMatch; s.g_btok = g.block_tokens;
+        s.g_nostore = nostore_bits + (size_t)c * kGeoNostoreWords;
+        for (uint32_t i = 0; i < kGeoNostoreWords; i++) s.g_nostore[i] = 0;
+        s.head = tables + (size_t)c * kGeoTableEntries; s.prev = s.head + (1u << cfg.hash_bits);
+    } else {
+        s.g_wsize = kWSize; s.g_hmask = kHashMask; s.g_hshift = 5; s.g_btok = kBlockTokens; s.g_nostore = nullptr;
+        s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
+    }
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
-    if (cfg.slow) lz_serial_chunk<true>(s); else lz_serial_chunk<false>(s);
+    if (cfg.slow) lz_serial_chunk<true, kGeo>(s); else lz_serial_chunk<false, kGeo>(s);
     meta[c].ntok = s.ntok; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
 }
 
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits)
 {
     // chunks per wave: measured best (MI355X, level 1) where the launch has about 4096 waves -- 16 per CU; 64 chunks per wave
     // (1024 waves at 4 GiB) is 30 % slower, 8192 waves again slower.  ZGPU_SERIAL_LANES overrides.
@@ -180,7 +217,8 @@ void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32
     if (forced < 0) { const char *e = getenv("ZGPU_SERIAL_LANES"); forced = e ? atoi(e) : 0; if (forced < 0 || forced > 64) forced = 0; }
     uint32_t lanes = (uint32_t)forced;
     if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
-    hipLaunchKernelGGL(lz_serial_kernel, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes);
+    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits);
+    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits);
 }
 
 } // namespace zgpu

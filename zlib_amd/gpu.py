@@ -66,6 +66,9 @@ def load_library():
     L.zgpu_version.restype = C.c_char_p
     L.zgpu_deflate_bound.argtypes = [u64, u32]
     L.zgpu_deflate_bound.restype = u64
+    L.zgpu_deflate_bound_geometry.argtypes = [u64, u32, C.c_int, C.c_int]
+    L.zgpu_deflate_bound_geometry.restype = u64
+    L.zgpu_deflate_set_geometry.argtypes = [vp, C.c_int, C.c_int]
     L.zgpu_deflate_device.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_host.argtypes = [vp, vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
@@ -159,7 +162,7 @@ class Engine:
         import numpy as np
         arr = np.frombuffer(data, dtype=np.uint8) if not hasattr(data, "ctypes") else data
         n = int(arr.size)
-        cap = self.L.zgpu_deflate_bound(n, chunk_size)
+        cap = self.L.zgpu_deflate_bound_geometry(n, chunk_size, *getattr(self, "geometry", (15, 8)))
         out = np.empty(cap, dtype=np.uint8)
         nchunks = max(1, (n + chunk_size - 1) // chunk_size)
         offs = np.zeros(nchunks + 1, dtype=np.uint64)
@@ -172,6 +175,11 @@ class Engine:
         z = out[: res.out_bytes].tobytes()
         return (z, offs) if want_offsets else z
 
+    def set_geometry(self, window_bits=15, mem_level=8):
+        """deflateInit2's windowBits (9..15) and memLevel (1..9) for the deflate calls that follow; 15 / 8 is the default."""
+        self._check(self.L.zgpu_deflate_set_geometry(self.h, window_bits, mem_level))
+        self.geometry = (window_bits, mem_level)
+
     def deflate_segments_host(self, buffers, level, flags=0, lz_impl=LZ_AUTO):
         """Batch of independent buffers (each <= 65536 bytes) -> list of raw-deflate segments, one launch."""
         import numpy as np
@@ -180,6 +188,8 @@ class Engine:
         offs[1:] = np.cumsum(sizes)
         blob = np.frombuffer(b"".join(buffers) + b"\0", dtype=np.uint8)
         cap = int(offs[-1]) + 40 * len(buffers) + 64
+        if getattr(self, "geometry", (15, 8)) != (15, 8):
+            cap = int(offs[-1]) + len(buffers) * (12288 + 5 * 520)
         out = np.empty(cap, dtype=np.uint8)
         ooffs = np.zeros(len(buffers) + 1, dtype=np.uint64)
         p = _Params(level, 0, flags, lz_impl)

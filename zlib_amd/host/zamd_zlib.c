@@ -122,13 +122,15 @@ static int multi_devices(void) /* engines ready for a fan-out (0: one device onl
 }
 
 struct multi_job { zgpu_engine *e; pthread_mutex_t *lock; const uint8_t *src; size_t n; zgpu_deflate_params p; uint8_t *dst; uint64_t cap; zgpu_deflate_result r; int rc;
-                   int tuned; uint32_t tune[4]; };
+                   int tuned; uint32_t tune[4]; int w_bits, mem_level; };
 static void *multi_worker(void *arg)
 {
     struct multi_job *j = (struct multi_job *)arg;
     pthread_mutex_lock(j->lock);
     zgpu_deflate_set_tuning(j->e, j->tuned, j->tune[0], j->tune[1], j->tune[2], j->tune[3]);
+    zgpu_deflate_set_geometry(j->e, j->w_bits, j->mem_level);
     j->rc = zgpu_deflate_host(j->e, j->src, j->n, &j->p, j->dst, j->cap, NULL, &j->r);
+    zgpu_deflate_set_geometry(j->e, 15, 8);
     zgpu_deflate_set_tuning(j->e, 0, 0, 0, 0, 0);
     pthread_mutex_unlock(j->lock);
     return NULL;
@@ -246,6 +248,7 @@ struct internal_state {
     size_t out_pos;   /* first undelivered byte of out */
     int trailer_done; /* deflate: Adler trailer already appended */
     int any_block;    /* deflate: at least one chunk has been emitted */
+    int w_bits, mem_level; /* deflateInit2's windowBits (9..15) and memLevel (1..9) */
     uint32_t dprime;  /* deflatePrime: (nbits << 16) | value, waiting for the next chunk that is emitted */
     uint32_t adler;   /* Adler-32 of the uncompressed data that went through the GPU (deflate) / was produced (inflate) */
     uint32_t crc;     /* the same for CRC-32 (gzip wrapper, wrap == 2) */
@@ -282,7 +285,9 @@ static uLong bound_for(uLong n)
 EXPORT uLong compressBound(uLong sourceLen) { return bound_for(sourceLen); }
 EXPORT uLong deflateBound(z_streamp strm, uLong sourceLen)
 {
-    const int gz = strm != Z_NULL && strm->state != Z_NULL && strm->state->kind == KIND_DEFLATE && strm->state->wrap == 2;
+    const int ours = strm != Z_NULL && strm->state != Z_NULL && strm->state->kind == KIND_DEFLATE, gz = ours && strm->state->wrap == 2;
+    if (ours && (strm->state->w_bits != 15 || strm->state->mem_level != 8)) /* short blocks, and blocks a small window cannot store (the arithmetic of deflate.c:513-515 per chunk) */
+        return (uLong)zgpu_deflate_bound_geometry(sourceLen, CHUNK, strm->state->w_bits, strm->state->mem_level) + 18;
     return bound_for(sourceLen) + (gz ? 12 : 0); /* 18 bytes of gzip framing instead of the 6 of zlib (deflate.c:520-534) */
 }
 
@@ -326,13 +331,13 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     int wrap = 1;
     if (windowBits < 0) { wrap = 0; windowBits = -windowBits; }
     else if (windowBits > 15) { wrap = 2; windowBits -= 16; } /* gzip wrapper, deflate.c:251-254 */
-    /* served subset: see include/zamd_zlib.h */
-    if (method != Z_DEFLATED || windowBits != 15 || memLevel != 8 || strategy < 0 || strategy > Z_FIXED || level < 0 || level > 9) return Z_STREAM_ERROR;
+    if (method != Z_DEFLATED || windowBits < 8 || windowBits > 15 || memLevel < 1 || memLevel > 9 || strategy < 0 || strategy > Z_FIXED || level < 0 || level > 9) return Z_STREAM_ERROR;
+    if (windowBits == 8) windowBits = 9; /* deflate.c:262: a 256-byte window is not served, the stream says 512 */
     if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
     struct internal_state *s = state_new(strm, KIND_DEFLATE);
     if (!s) return Z_MEM_ERROR;
     strm->state = s;
-    s->wrap = wrap; s->level = level; s->strategy = strategy;
+    s->wrap = wrap; s->level = level; s->strategy = strategy; s->w_bits = windowBits; s->mem_level = memLevel;
     return deflateReset(strm);
 }
 EXPORT int deflateInit_(z_streamp strm, int level, const char *version, int stream_size)
@@ -365,7 +370,7 @@ EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
     if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || s->any_block || s->in.len != 0 || strm->total_in != 0) return Z_STREAM_ERROR;
     if (s->wrap) strm->adler = adler32(strm->adler, d, n); /* becomes the DICTID of the header */
     if (n < 3) return Z_OK;                                /* shorter than MIN_MATCH: nothing to match against */
-    const uInt keep = n > 32506u ? 32506u : n;            /* MAX_DIST: the tail of the dictionary */
+    const uInt max_dist = (1u << s->w_bits) - 262u, keep = n > max_dist ? max_dist : n; /* MAX_DIST: the tail of the dictionary (deflate.c:337-340) */
     s->dict.len = 0;
     if (!buf_put(&s->dict, d + (n - keep), keep)) return Z_MEM_ERROR;
     s->dict_pending = 1;
@@ -448,20 +453,46 @@ static int stored_block(bytebuf *out, const uint8_t *src, size_t len, int last, 
     *prime = 0;
     return buf_put(out, h, nh) && buf_put(out, l, 4) && buf_put(out, src, len);
 }
-static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final, uint32_t *prime)
+/* One chunk as deflate_stored cuts it (deflate.c:1390-1439) when the whole chunk is at hand and the output has room: the window of 2 << w_bits bytes is
+ * filled (fill_window, :1265-1350: sliding by a window when strstart has reached wsize + MAX_DIST), everything buffered joins the block, a block is closed
+ * when it reaches max_block_size = min(0xffff, pending_buf_size - 5) and again when it reaches MAX_DIST, and the flush at the end closes whatever is left --
+ * an EMPTY block after a cut that took everything.  `dict`: the window starts with that many dictionary bytes (deflateSetDictionary, :347-348). */
+static int stored_one_chunk(bytebuf *out, const uint8_t *src, size_t len, int last, uint32_t *prime, int w_bits, int mem_level, size_t dict)
+{
+    const long W = 1L << w_bits, MAXD = W - 262, pend = 4L << (mem_level + 6), maxblk = pend - 5 < 0xffff ? pend - 5 : 0xffff;
+    long str = (long)dict, blk = (long)dict, look = 0, avail = (long)len, slid = 0; /* window indices; data offset of index i = i - dict + slid */
+    for (;;) {
+        if (look <= 1) {
+            do {
+                long more = 2 * W - look - str;
+                if (str >= W + MAXD) { str -= W; blk -= W; slid += W; more += W; }
+                if (avail == 0) break;
+                const long take = avail < more ? avail : more;
+                avail -= take; look += take;
+            } while (look < 262 && avail != 0);
+            if (look == 0) break;
+        }
+        str += look; look = 0;
+        const long max_start = blk + maxblk;
+        if (str == 0 || str >= max_start) {
+            look = str - max_start; str = max_start;
+            if (!stored_block(out, src + (blk - (long)dict + slid), (size_t)(str - blk), 0, prime)) return 0;
+            blk = str;
+        }
+        if (str - blk >= MAXD) {
+            if (!stored_block(out, src + (blk - (long)dict + slid), (size_t)(str - blk), 0, prime)) return 0;
+            blk = str;
+        }
+    }
+    return stored_block(out, src + (blk - (long)dict + slid), (size_t)(str - blk), last, prime);
+}
+static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final, uint32_t *prime, int w_bits, int mem_level, size_t dict)
 {
     size_t nchunks = n ? (n + CHUNK - 1) / CHUNK : 1;
     for (size_t k = 0; k < nchunks; k++) {
         const size_t lo = k * CHUNK, len = n - lo < CHUNK ? n - lo : CHUNK;
         const int last = final && k + 1 == nchunks;
-        int ok;
-        /* what deflate_stored emits for a fresh stream of `len` bytes: a block is cut at 65531 bytes (pending_buf_size - 5,
-         * deflate.c:1397-1402,1420-1427) or as soon as it reaches MAX_DIST = 32506 bytes (:1431-1434), and the flush at the end
-         * then closes whatever is left -- an EMPTY block after a MAX_DIST cut that took everything */
-        if (len > 65531) ok = stored_block(out, src + lo, 65531, 0, prime) && stored_block(out, src + lo + 65531, len - 65531, last, prime);
-        else if (len >= 32506) ok = stored_block(out, src + lo, len, 0, prime) && stored_block(out, src + lo, 0, last, prime);
-        else ok = stored_block(out, src + lo, len, last, prime);
-        if (!ok) return 0;
+        if (!stored_one_chunk(out, src + lo, len, last, prime, w_bits, mem_level, k == 0 ? dict : 0)) return 0;
         if (!last) { static const uint8_t marker[5] = {0, 0, 0, 0xff, 0xff}; if (!buf_put(out, marker, 5)) return 0; }
     }
     return 1;
@@ -479,20 +510,22 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
         const int first_final = final && take == n;
         s->dict_pending = 0;
         if (s->level == 0) {
-            if (!stored_chunks(&s->out, src, take, first_final, &s->dprime)) return Z_MEM_ERROR;
+            if (!stored_chunks(&s->out, src, take, first_final, &s->dprime, s->w_bits, s->mem_level, s->dict.len)) return Z_MEM_ERROR;
             s->adler = (uint32_t)adler32(s->adler, src, (uInt)take);
         } else {
             if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
             bytebuf w = {0};
             if (!buf_put(&w, s->dict.p, s->dict.len) || !buf_put(&w, src, take)) { free(w.p); return Z_MEM_ERROR; }
-            const uint64_t cap = zgpu_deflate_bound(w.len, CHUNK);
+            const uint64_t cap = zgpu_deflate_bound_geometry(w.len, CHUNK, s->w_bits, s->mem_level);
             if (!buf_reserve(&s->out, cap)) { free(w.p); return Z_MEM_ERROR; }
             zgpu_deflate_params p = {s->level, CHUNK, first_final ? ZGPU_F_FINAL : 0u, ZGPU_LZ_AUTO, s->strategy, s->dprime};
             s->dprime = 0;
             zgpu_deflate_result r;
             zgpu_engine *e = engine_checkout();
             zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+            zgpu_deflate_set_geometry(e, s->w_bits, s->mem_level);
             int rc = zgpu_deflate_dict_chunk_host(e, w.p, (uint32_t)w.len, (uint32_t)s->dict.len, &p, s->out.p + s->out.len, cap, &r);
+            zgpu_deflate_set_geometry(e, 15, 8);
             zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
             engine_checkin(e);
             free(w.p);
@@ -507,7 +540,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
         src += take; n -= take;
     }
     if (s->level == 0) {
-        if (!stored_chunks(&s->out, src, n, final, &s->dprime)) return Z_MEM_ERROR;
+        if (!stored_chunks(&s->out, src, n, final, &s->dprime, s->w_bits, s->mem_level, 0)) return Z_MEM_ERROR;
         for (size_t o = 0; o < n; o += 0x40000000u) {
             size_t m = n - o < 0x40000000u ? n - o : 0x40000000u;
             if (s->wrap == 2) s->crc = (uint32_t)crc32(s->crc, src + o, (uInt)m); else s->adler = (uint32_t)adler32(s->adler, src + o, (uInt)m);
@@ -516,7 +549,7 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     }
     zgpu_engine *e = engine_get();
     if (!e) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
-    uint64_t cap = zgpu_deflate_bound(n, CHUNK);
+    uint64_t cap = zgpu_deflate_bound_geometry(n, CHUNK, s->w_bits, s->mem_level);
     const int ndev = n >= ((size_t)64 << 20) ? multi_devices() : 0; /* (a fan-out pays from 32 MiB per device on) */
     if (ndev > 1) {
         struct multi_job job[ZAMD_MAX_DEVICES];
@@ -532,8 +565,8 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
             struct multi_job *j = &job[d];
             j->e = g_multi[d]; j->lock = &g_multi_lock[d]; j->src = src + b0; j->n = b1 - b0;
             j->p = (zgpu_deflate_params){s->level, CHUNK, ((final && d + 1 == used) ? ZGPU_F_FINAL : 0u) | (s->wrap == 2 ? ZGPU_F_CRC32 : 0u), ZGPU_LZ_AUTO, s->strategy, d == 0 ? s->dprime : 0u};
-            j->cap = zgpu_deflate_bound(j->n, CHUNK); j->dst = s->out.p + s->out.len + at; at += j->cap;
-            j->tuned = s->tuned; memcpy(j->tune, s->tune, sizeof j->tune); j->rc = ZGPU_ERRNO;
+            j->cap = zgpu_deflate_bound_geometry(j->n, CHUNK, s->w_bits, s->mem_level); j->dst = s->out.p + s->out.len + at; at += j->cap;
+            j->tuned = s->tuned; memcpy(j->tune, s->tune, sizeof j->tune); j->w_bits = s->w_bits; j->mem_level = s->mem_level; j->rc = ZGPU_ERRNO;
         }
         s->dprime = 0;
         int started = 0;
@@ -560,7 +593,9 @@ static int run_chunks(z_streamp strm, const uint8_t *src, size_t n, int final)
     zgpu_deflate_result r;
     e = engine_checkout();
     zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+    zgpu_deflate_set_geometry(e, s->w_bits, s->mem_level);
     int rc = zgpu_deflate_host(e, src, n, &p, s->out.p + s->out.len, cap, NULL, &r);
+    zgpu_deflate_set_geometry(e, 15, 8);
     zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
     engine_checkin(e);
     if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
@@ -603,7 +638,7 @@ EXPORT int deflate(z_streamp strm, int flush)
         s->status = ST_BUSY;
     }
     if (s->status == ST_INIT) { /* zlib header, deflate.c:625-649 */
-        unsigned hdr = (Z_DEFLATED + (7u << 4)) << 8, lf = (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
+        unsigned hdr = (Z_DEFLATED + ((unsigned)(s->w_bits - 8) << 4)) << 8, lf = (s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 0 : s->level < 6 ? 1 : s->level == 6 ? 2 : 3;
         hdr |= lf << 6;
         if (s->dict_pending) hdr |= 0x20; /* PRESET_DICT, deflate.c:641 */
         hdr += 31 - hdr % 31;
