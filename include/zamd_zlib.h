@@ -11,13 +11,15 @@
  *     exactly as the reference compresses a fresh raw stream of that chunk, separated by full-flush markers.
  *     It is a valid RFC 1950 stream that any inflate() reads; it is not byte-identical to the reference's
  *     unchunked output, whose matches cross 64 KiB boundaries.
- *   - Served parameters: method Z_DEFLATED, windowBits 15 (zlib wrapper), -15 (raw) or 31 (gzip wrapper; inflate also 47 =
- *     zlib or gzip, detected, and any window size 8..15 a header may declare), memLevel 8, all five strategies, levels 0..9 and
+ *   - Served parameters: method Z_DEFLATED, windowBits 8..15 (zlib wrapper), -8..-15 (raw) or 24..31 (gzip wrapper; inflate also 40..47 =
+ *     zlib or gzip, detected, and any window size 8..15 a header may declare), memLevel 1..9, all five strategies, levels 0..9 and
  *     Z_DEFAULT_COMPRESSION, deflateParams, deflateTune, deflateSetHeader / inflateGetHeader, deflateCopy / inflateCopy, preset
  *     dictionaries (set before the first input byte), inflateSync / inflateSyncPoint, inflatePrime (raw streams), the gz* file
- *     functions and inflateBack*.  deflateInit2 with another windowBits or memLevel returns Z_STREAM_ERROR (they change the hash
- *     size and the block cut of the reference's output, which the chunk kernels do not model); deflatePrime accepts 0 bits only
- *     (a stream that starts inside a byte moves every alignment padding of the first chunk).
+ *     functions and inflateBack*.  A deflateInit2 geometry other than windowBits 15 / memLevel 8 changes the window the matches live in,
+ *     the hash and the block cut of the reference's output: such streams are bit-exact too (every chunk = the reference's chunk function
+ *     under that deflateInit2) and are served by the engine's general lane-per-chunk kernel, not by the kernels built for the default
+ *     geometry (tests/golden/geometry_kat.json: all 63 geometries).  deflatePrime: up to 16 bits in front of the next chunk that is
+ *     emitted (tests/golden/prime_kat.json); refused while input waits for its chunk to fill.
  *   - Z_SYNC_FLUSH and Z_PARTIAL_FLUSH end the pending chunk like Z_FULL_FLUSH: the marker is the same 00 00 FF FF, the chunk
  *     behind it simply does not refer back across it (a decoder cannot tell; the reference would keep its window).
  *   - inflate() hands out data per full-flush segment: output appears when a segment (or the stream) is complete, and a stream
@@ -140,7 +142,7 @@ int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
 int deflateParams(z_streamp strm, int level, int strategy);
 int deflateCopy(z_streamp dest, z_streamp source);
 int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain);
-int deflatePrime(z_streamp strm, int bits, int value); /* bits == 0 only */
+int deflatePrime(z_streamp strm, int bits, int value);
 int deflateSetHeader(z_streamp strm, gz_headerp head);
 
 int inflateInit_(z_streamp strm, const char *version, int stream_size);

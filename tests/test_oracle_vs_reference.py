@@ -96,3 +96,24 @@ def test_prime_golden_file_is_what_the_reference_writes_now():
     for c in kat[::5]:
         z = G.ref_primed(L, cases.make(c["kind"], c["n"], c["seed"]), c["level"], c["wbits"], tuple(c["prime"]), tuple(c["mid"]) if c["mid"] else None)
         assert len(z) == c["len"] and hashlib.sha256(z).hexdigest()[:16] == c["sha"]
+
+
+def test_geometry_and_fullblock_golden_files_are_what_the_reference_writes_now():
+    """tests/golden/geometry_kat.json and fullblock_kat.json against the compiled reference (a sample of the former, all of the latter)."""
+    import hashlib
+    import json
+    from oracle import gen_golden_fullblock as F, gen_golden_geometry as G
+    L = R.lib()
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    kat = json.load(open(os.path.join(gold, "geometry_kat.json")))
+    assert len(kat["chunk"]) == 7 * 9 * len(G.LEVELS) * 4
+    for c in kat["chunk"][::23]:
+        d = cases.make(c["kind"], c["n"], c["seed"])
+        for last in (0, 1):
+            z = G.ref_chunk(L, d, c["level"], c["w"], c["m"], bool(last))
+            assert (len(z), hashlib.sha256(z).hexdigest()[:16]) == (c["len"][last], c["sha"][last])
+    ins = dict(F.inputs())
+    for c in json.load(open(os.path.join(gold, "fullblock_kat.json"))):
+        for last in (0, 1):
+            z = R.deflate_chunk_raw(ins[c["name"]], c["level"], bool(last))
+            assert (len(z), hashlib.sha256(z).hexdigest()[:16]) == (c["len"][last], c["sha"][last])
