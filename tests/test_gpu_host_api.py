@@ -33,8 +33,11 @@ def test_version_and_errors():
     assert L.deflateInit_(C.byref(s), 6, b"2.0", C.sizeof(Z.ZStream)) == Z.Z_VERSION_ERROR      # deflate.c:236-239
     assert L.deflateInit_(C.byref(s), 6, b"1.2.3", 100) == Z.Z_VERSION_ERROR
     assert L.deflateInit_(C.byref(s), 10, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR
-    assert L.deflateInit2_(C.byref(s), 6, 8, 14, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # window sizes other than 32 KiB: not served
-    assert L.deflateInit2_(C.byref(s), 6, 8, 15, 9, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR  # memLevel 9 changes the block cut: not served
+    assert L.deflateInit2_(C.byref(s), 6, 8, 7, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR   # deflate.c:258-261: windowBits 8..15,
+    assert L.deflateInit2_(C.byref(s), 6, 8, 15, 10, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR # memLevel 1..9 (all served: tests/test_gpu_geometry.py)
+    assert L.deflateInit2_(C.byref(s), 6, 8, 15, 0, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_STREAM_ERROR
+    assert L.deflateInit2_(C.byref(s), 6, 8, 14, 9, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
+    assert L.deflateEnd(C.byref(s)) == Z.Z_OK
     assert L.deflateInit2_(C.byref(s), 6, 8, 31, 8, 0, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK            # gzip wrapper (tests/test_gpu_gzip.py)
     assert L.deflateEnd(C.byref(s)) == Z.Z_OK
     assert L.deflateInit_(C.byref(s), 6, b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK

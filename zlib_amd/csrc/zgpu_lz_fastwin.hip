@@ -65,6 +65,7 @@ __device__ inline uint32_t fw_lds_base(const void *p) { return (uint32_t)(uintpt
 // 8 / 4 bytes at any LDS byte offset (the hardware serves unaligned ds reads; their 36 clocks in the LDS cost one issue slot)
 __device__ inline uint64_t fw_ld64(uint32_t a) { uint64_t v; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory"); return v; }
 __device__ inline uint32_t fw_ld32(uint32_t a) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(a) : "memory"); return v; }
+__device__ inline void fw_ld32x2(uint32_t a, uint32_t b, uint32_t &x, uint32_t &y) { asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(a), "v"(b) : "memory"); }
 __device__ inline void fw_ld64x2(uint32_t a, uint32_t b, uint64_t &x, uint64_t &y)
 {
     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x), "=&v"(y) : "v"(a), "v"(b) : "memory");
@@ -251,43 +252,54 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
             }
             FW_LAP(2);
             // ---- the walk over the token starts, from `start` ----
+            // What the scalar loop needs of a lane comes packed: where the token behind this lane's starts (lane + length, unclamped) and the two flags.
+            // Whether a match's strings stay out of the chains is a mask of its own (a measured match is NICE or longer, i.e. longer than
+            // max_insert_length at the three levels this kernel serves), and the positions inside such matches (C) are found by all lanes behind the loop.
             const uint64_t nonlit = __builtin_amdgcn_ballot_w64(res != 1u);
-            uint64_t T = 0, C = 0;
-            uint32_t L = start, stop_inc = 64;
-            bool cs_new = cross_short;
+            uint32_t pk = (lane + (res & kResLen)) | (res & (kResTerm | kResInc));
+            const uint32_t len_e = res & kResLen;
+            const uint64_t longm = __builtin_amdgcn_ballot_w64(len_e >= kMinMatch && !(len_e <= max_insert && n - p - len_e >= kMinMatch));
+            uint64_t T = 0;
+            uint32_t L = start, stop_inc = 64, Llast = 64;
             while (L < lend) {
                 const uint64_t ahead = nonlit >> L;
-                const uint32_t run = ahead ? (uint32_t)__builtin_ctzll(ahead) : 64u; // literals up to the next lane with a match
-                const uint32_t Lm = L + run < lend ? L + run : lend;
-                if (Lm > L) T |= (Lm - L >= 64 ? ~0ull : ((1ull << (Lm - L)) - 1ull)) << L;
-                L = Lm;
-                if (L >= lend) break;
-                uint32_t x = __builtin_amdgcn_readlane(res, L);
-                if (x & kResInc) { stop_inc = L; break; }
-                T |= 1ull << L;
-                uint32_t len = x & kResLen;
-                const uint32_t p0 = w0 + L;
-                if (x & kResTerm) FW_CNT(11, 1);
-                if (x & kResTerm) { // all lanes measure the match: four bytes each behind the NICE the lane has compared
-                    const uint32_t q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
+                if (ahead == 0) { T |= (~0ull << L) & (lend >= 64 ? ~0ull : (1ull << lend) - 1ull); L = lend; Llast = 64; break; } // literals to the end of the window
+                const uint32_t run = (uint32_t)__builtin_ctzll(ahead); // literals up to the next lane with a match (a lane below lend: others hold 1)
+                T |= ((1ull << run) - 1ull) << L;
+                L += run;
+                uint32_t x = __builtin_amdgcn_readlane(pk, L);
+                if (x & (kResInc | kResTerm)) {
+                    if (x & kResInc) { stop_inc = L; break; }
+                    FW_CNT(11, 1);
+                    // all lanes measure the match: four bytes each behind the NICE the lane has compared
+                    const uint32_t p0 = w0 + L, q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
                     const uint32_t o = NICE + 4 * lane;
-                    const uint32_t xa = fw_ld32(ring_a + fw_ring(q0 + o)) ^ fw_ld32(ring_a + fw_ring(p0 + o));
+                    uint32_t xa, xb;
+                    fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
+                    xa ^= xb;
                     const uint64_t ne = __builtin_amdgcn_ballot_w64(xa != 0);
-                    if (ne == 0) len = cap0;
-                    else {
+                    uint32_t len = cap0;
+                    if (ne != 0) {
                         const uint32_t f = (uint32_t)__builtin_ctzll(ne), xf = __builtin_amdgcn_readlane(xa, f);
                         len = NICE + 4 * f + ((uint32_t)__builtin_ctz(xf) >> 3);
                         len = len < cap0 ? len : cap0;
                     }
                     res = lane == L ? len : res; // (the length is known now, whatever becomes of this round)
+                    pk = lane == L ? L + len : pk;
+                    x = L + len;
                 }
-                const bool sh = len <= max_insert && n - p0 - len >= kMinMatch;
-                if (!sh) { // the strings inside this match stay out of the chains
-                    const uint32_t e = L + len < 64 ? L + len : 64;
-                    if (e > L + 1) C |= ((1ull << (e - L - 1)) - 1ull) << (L + 1);
-                }
-                if (L + len >= 64) cs_new = sh;
-                L += len;
+                T |= 1ull << L;
+                Llast = L;
+                L = x & kResLen;
+            }
+            bool cs_new = cross_short;
+            if (L >= 64 && Llast < 64) cs_new = !((longm >> Llast) & 1ull); // the match that reaches into the next window
+            uint64_t C = 0;
+            {
+                const uint64_t below = T & lanes_below; // the token starts in front of this lane
+                const uint32_t owner = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                const bool inside = below != 0 && !(T & lane_bit) && lane < L && ((longm >> owner) & 1ull);
+                C = __builtin_amdgcn_ballot_w64(inside);
             }
             FW_LAP(3);
             // ---- which of these tokens stand ----
