@@ -120,6 +120,7 @@ int zgpu_engine_create(int device, zgpu_engine **out);
 void zgpu_engine_destroy(zgpu_engine *e);
 const char *zgpu_engine_error(const zgpu_engine *e);
 const char *zgpu_version(void);
+uint64_t zgpu_debug_handed_on(const zgpu_engine *e); /* diagnostic: chunks of level 1-3 calls that went from the lane-per-chunk loop to the wave-per-chunk kernel */
 
 /* deflateInit2's geometry (qcsrc/deflate.c:222-297) for the calls that follow: windowBits 9..15 (the window is 2^windowBits bytes, matches reach
  * 2^windowBits - 262 back, the window slides every 2^windowBits bytes) and memLevel 1..9 (hash of memLevel + 7 bits, a block is cut after

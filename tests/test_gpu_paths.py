@@ -65,3 +65,34 @@ def test_alternative_paths_agree():
     for env in ({"ZGPU_SORT": "1"}, {"ZTEST_SORT_FAULT": "1"}, {"ZGPU_PARSE": "1"}, {"ZGPU_SORT": "1", "ZGPU_PARSE": "1"}, {"ZGPU_BATCH_CHUNKS": "7"}):
         got = run_variant(env)
         assert got == base, "variant %r differs: %s" % (env, [k for k in base if got.get(k) != base[k]])
+
+
+def test_chunks_the_loop_hands_on_come_out_the_same(monkeypatch):
+    """Levels 1-3, large calls: the lane-per-chunk loop gives chunks that do not compress to the wave-per-chunk kernel (lz_serial_chunk's hand_on, a list
+    launch of sort3 + fastwin over ChunkGeom::chunk_map).  Forced here at test size (ZGPU_HAND_ON=2): a call of compressible, incompressible and
+    half-and-half chunks, ragged at the end, against the same call with the hand-on switched off and against the oracle; the counter says it happened."""
+    import ctypes as C
+    import numpy as np
+    import zlib_amd
+    from zlib_amd import gpu
+    from oracle import cases, corpus_py as CP, oracle_py as O
+    parts = [CP.chunks(CP.KIND_SILESIA, 5, 6).reshape(-1).tobytes(), cases.make("rand", 3 * 65536, 9), cases.make("text", 65536, 3),
+             cases.make("rand", 40000, 4) + cases.make("text", 25536, 5), cases.make("text", 30000, 6) + cases.make("rand", 35536, 7),
+             cases.make("rand", 65536, 8), cases.make("mix", 65536, 10), cases.make("rand", 12345, 11)]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    e = zlib_amd.Engine(0)
+    e.L.zgpu_debug_handed_on.argtypes = [C.c_void_p]
+    e.L.zgpu_debug_handed_on.restype = C.c_uint64
+    try:
+        for level in (1, 2, 3):
+            plain, offs = e.deflate_host(data, level, want_offsets=True, lz_impl=gpu.LZ_SERIAL)  # (asked for by name, the loop keeps every chunk)
+            monkeypatch.setenv("ZGPU_HAND_ON", "2")
+            before = e.L.zgpu_debug_handed_on(e.h)
+            handed, offs2 = e.deflate_host(data, level, want_offsets=True)
+            n_handed = e.L.zgpu_debug_handed_on(e.h) - before
+            assert handed == plain and list(offs) == list(offs2)
+            assert 5 <= n_handed <= 7, n_handed  # the chunks that begin with random bytes
+            assert handed == O.deflate_stream(data.tobytes(), level)
+            monkeypatch.delenv("ZGPU_HAND_ON")
+    finally:
+        e.close()

@@ -22,7 +22,9 @@ constexpr uint32_t kGeoSlotStride = 65536 + 8192 + 1024 + 64 + 5 * 32 * kGeoNost
 constexpr uint32_t kMaxBlocks = 6;
 // ChunkMeta::nostore bit 31: deflate_slow tallies the last byte's literal behind its loop without looking at "buffer full" (deflate.c:1660-1665), so when that
 // literal is the token that fills a block, the block is flushed as the chunk's LAST one -- there is no empty block behind it
-constexpr uint32_t kFullFinalBlock = 1u << 31;             // ceil(65536/16383) + a possible empty final block
+constexpr uint32_t kFullFinalBlock = 1u << 31;
+// ChunkMeta::ntok of a chunk the lane-per-chunk loop has handed on (see lz_serial_kernel): no tokens yet, the wave-per-chunk kernel takes it
+constexpr uint32_t kHandedOn = 0xFFFFFFFFu;             // ceil(65536/16383) + a possible empty final block
 constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCodes + 1, kMaxBits = 15, kMaxBLBits = 7;
 constexpr int kEndBlock = 256;
 constexpr uint32_t kSlotStride = 65536 + 256;  // per-chunk output slot (worst case: 5 stored blocks + marker = +30)
@@ -66,17 +68,21 @@ struct ChunkGeom {
     uint32_t block_tokens;   // lit_bufsize - 1: a block is cut after this many tokens (kBlockTokens by default)
     uint32_t slot_stride;    // bytes between the chunks' output slots (kSlotStride by default)
     const uint32_t *nostore_bits; // nullptr: ChunkMeta::nostore has a bit per block; else kGeoNostoreWords words per chunk (a chunk may have 517 blocks)
+    // A launch over a LIST of the batch's chunks (levels 1-3: the chunks the lane-per-chunk loop handed on, zgpu_engine.hip): workgroup c works on
+    // chunk chunk_map[c] of the batch -- the input, tokens and meta of that chunk; its scratch (sorted buckets) is slot c.  nullptr: chunk c.
+    const uint32_t *chunk_map;
 };
+__device__ inline uint32_t chunk_of(const ChunkGeom &g, uint32_t c) { return g.chunk_map ? g.chunk_map[c] : c; }
 __device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, uint32_t &n)
 {
-    const uint64_t gc = g.chunk0 + c;
+    const uint64_t gc = g.chunk0 + chunk_of(g, c);
     if (g.seg_off) { lo = g.seg_off[gc]; n = (uint32_t)(g.seg_off[gc + 1] - lo); }
     else { lo = gc * g.chunk_size; uint64_t rem = g.in_bytes - lo; n = (uint32_t)(rem < g.chunk_size ? rem : g.chunk_size); }
 }
-__device__ inline bool chunk_is_final(const ChunkGeom &g, uint32_t c) { return g.all_final || g.chunk0 + c == g.final_chunk; }
-__device__ inline uint32_t chunk_skip(const ChunkGeom &g, uint32_t c) { return g.chunk0 + c == 0 ? g.skip0 : 0u; }
-__device__ inline uint32_t chunk_prime(const ChunkGeom &g, uint32_t c) { return g.chunk0 + c == 0 ? g.prime : 0u; }
-__device__ inline uint32_t chunk_base(const ChunkGeom &g, uint32_t c) { return (g.pos0_mode == 2 || (g.pos0_mode == 1 && g.chunk0 + c != 0)) ? 3u : 0u; }
+__device__ inline bool chunk_is_final(const ChunkGeom &g, uint32_t c) { return g.all_final || g.chunk0 + chunk_of(g, c) == g.final_chunk; }
+__device__ inline uint32_t chunk_skip(const ChunkGeom &g, uint32_t c) { return g.chunk0 + chunk_of(g, c) == 0 ? g.skip0 : 0u; }
+__device__ inline uint32_t chunk_prime(const ChunkGeom &g, uint32_t c) { return g.chunk0 + chunk_of(g, c) == 0 ? g.prime : 0u; }
+__device__ inline uint32_t chunk_base(const ChunkGeom &g, uint32_t c) { return (g.pos0_mode == 2 || (g.pos0_mode == 1 && g.chunk0 + chunk_of(g, c) != 0)) ? 3u : 0u; }
 
 // token: bits 0..7 = literal byte or (match length - 3); bits 8..23 = match distance (0 for a literal)
 __host__ __device__ inline uint32_t tok_lit(uint32_t c) { return c; }

@@ -14,7 +14,8 @@ namespace zgpu {
 struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 // kernels (other translation units)
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits);
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on = false);
+void launch_collect_handed_on(const ChunkMeta *meta, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t st);
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
 void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
@@ -55,6 +56,8 @@ struct zgpu_engine {
     uint32_t tables_cap = 0;
     void *par_ws = nullptr;      // parallel LZ only
     int tuned = 0; uint32_t tune[4] = {0, 0, 0, 0}; // zgpu_deflate_set_tuning: good, lazy, nice, chain instead of the level's
+    uint64_t handed_on = 0; // (diagnostic: chunks handed on since the engine was made)
+    uint32_t *hand_list = nullptr; uint32_t hand_cap = 0; // chunks the lane-per-chunk loop handed on: [0] their number, [1..] their indices in the batch
     int geo_w = 15, geo_m = 8;   // zgpu_deflate_set_geometry: deflateInit2's windowBits and memLevel
     uint8_t *geo_slots = nullptr; uint16_t *geo_tables = nullptr; uint32_t *geo_nostore = nullptr; uint32_t geo_cap = 0; // the workspace of a non-default geometry
     int exact_sort = 0;          // sticky: the fast sort's self-check failed once on this engine (zgpu_lz_sorted.hip, pass V)
@@ -216,6 +219,8 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // the parse-driven search plays deflate_slow's own game; the two strategies that are chain budgets of the all-position search
     // (Z_HUFFMAN_ONLY, Z_RLE) stay with that search
     const bool walk_ok = cfg.strategy != kHuffmanOnly && cfg.strategy != kRle;
+    // levels 1-3 above the crossover: the lane-per-chunk loop hands the chunks that do not compress on to the wave-per-chunk kernel (lz_serial_chunk)
+    bool hand_on = false;
     if (impl == ZGPU_LZ_AUTO) {
         static int auto_env = -1; // ZGPU_LZ_DEFAULT=3: A/B runs of the all-position search
         if (auto_env < 0) { const char *v = getenv("ZGPU_LZ_DEFAULT"); auto_env = v ? atoi(v) : 0; }
@@ -227,9 +232,17 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         // CU; the lane-per-chunk loop takes 28 ms a chunk and needs tens of thousands of them in flight.  Measured crossovers (chunks per call, 4 GiB =
         // 65536): level 1 about 40000, level 2 about 28000, level 3 (32 candidates a lane) about 4000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) {
-            const uint64_t cs0 = p->chunk_size ? p->chunk_size : kChunkMax, nch0 = d_seg ? nseg : (in_bytes + cs0 - 1) / cs0;
+            const uint64_t cs0 = p->chunk_size ? p->chunk_size : kChunkMax;
+            uint64_t nch0 = d_seg ? nseg : (in_bytes + cs0 - 1) / cs0;
+            { // what counts is the chunks of ONE launch: host input goes batch by batch (see below), and every batch of the loop would pay its latency again
+                const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 16384) : env_u32("ZGPU_BATCH_CHUNKS", 65536);
+                if (per_launch && nch0 > per_launch) nch0 = per_launch;
+            }
             const uint64_t upto = cfg.chain == 4 ? 36864 : cfg.chain == 8 ? 24576 : 4096;
-            if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;
+            const char *ho = getenv("ZGPU_HAND_ON"); // 0: the loop keeps every chunk (A/B runs); 2: the loop + hand-on whatever the size of the call (tests)
+            if (ho && ho[0] == '2' && auto_env == 0) hand_on = true;
+            else if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;
+            else hand_on = !(ho && ho[0] == '0');
         }
     }
     if ((impl == ZGPU_LZ_PARALLEL || impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK) && (!cfg.slow || !lz_parallel_available()))
@@ -247,6 +260,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     }
     if (geo) impl = ZGPU_LZ_SERIAL;
     const bool serial = impl == ZGPU_LZ_SERIAL;
+    hand_on = hand_on && serial && !geo && p->lz_impl == ZGPU_LZ_AUTO;
     if (d_seg && ((p->flags & (ZGPU_F_ZLIB_WRAP | ZGPU_F_GZIP_WRAP)) || nseg == 0)) return fail(e, ZGPU_STREAM_ERROR, "segment mode: no zlib wrapper, nseg >= 1");
     const uint64_t nchunks = d_seg ? nseg : (in_bytes ? (in_bytes + chunk_size - 1) / chunk_size : 1);
     // One batch = one launch of every stage.  The lane-per-chunk stages (serial LZ77, parse) need tens of thousands of
@@ -260,7 +274,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)(kHashSize + kWSize) * 2 : lz_sorted_workspace_bytes(1));
+        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)(kHashSize + kWSize) * 2 + (hand_on ? lz_sorted_workspace_bytes(1) : 0) : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
@@ -272,6 +286,14 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
     int rc = ensure_deflate_ws(e, batch, serial, nchunks, geo);
     if (rc) return rc;
+    if (hand_on) {
+        if ((rc = ensure_deflate_ws(e, batch, false, nchunks))) return rc; // the sorted buckets' workspace as well (every chunk may be handed on)
+        if (batch > e->hand_cap) {
+            hipFree(e->hand_list); e->hand_list = nullptr; e->hand_cap = 0;
+            if ((rc = dev_alloc(e, &e->hand_list, (size_t)batch + 1))) return rc;
+            e->hand_cap = batch;
+        }
+    }
     const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP, gz = p->flags & ZGPU_F_GZIP_WRAP;
     const uint32_t head_bytes = wrap ? 2 : gz ? 10 : 0, tail_bytes = wrap ? 4 : gz ? 8 : 0;
     ChunkGeom g{};
@@ -289,7 +311,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 
     RunStateHost rs{}; rs.out_total = head_bytes; rs.adler_a = 1; rs.adler_b = 0; rs.data_type = 2;
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
-    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN) && !e->exact_sort;
+    const bool check_sort = (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN || hand_on) && !e->exact_sort;
     uint32_t sort_fault = 0;
     if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
     if (wrap && out_cap >= 2) { uint8_t hdr[2]; zlib_header(p->level, p->strategy, hdr); ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, 2, hipMemcpyHostToDevice, st)); }
@@ -358,7 +380,18 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
                 launch_lz_serial(g, cfg, e->geo_tables, e->tokens, e->meta, st, e->geo_nostore);
             } else {
                 ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
-                launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr);
+                launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr, hand_on);
+            }
+            if (hand_on) { // the chunks the loop gave up, as a list, through the wave-per-chunk kernel (their number decides the launch: one word comes home)
+                launch_collect_handed_on(e->meta, nb, e->hand_list + 1, e->hand_list, st);
+                uint32_t handed = 0;
+                ZGPU_HIP_CHECK(hipMemcpyAsync(&handed, e->hand_list, 4, hipMemcpyDeviceToHost, st));
+                ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+                if (handed) {
+                    ChunkGeom gl = g; gl.nchunks = handed; gl.chunk_map = e->hand_list + 1;
+                    launch_lz_sorted(gl, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, 3);
+                }
+                e->handed_on += handed;
             }
         } else {
             if (impl == ZGPU_LZ_SORTED || impl == ZGPU_LZ_WALK || impl == ZGPU_LZ_FAST || impl == ZGPU_LZ_FASTWIN)
@@ -477,7 +510,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     if (!e) return;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
-    hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
+    hipFree(e->hand_list); hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
@@ -490,6 +523,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
 }
 
 const char *zgpu_engine_error(const zgpu_engine *e) { return e ? e->err : "no engine"; }
+uint64_t zgpu_debug_handed_on(const zgpu_engine *e) { return e ? e->handed_on : 0; } // chunks the lane-per-chunk loop gave to the wave-per-chunk kernel so far (tests, bench)
 
 uint64_t zgpu_deflate_bound(uint64_t in_bytes, uint32_t chunk_size)
 {

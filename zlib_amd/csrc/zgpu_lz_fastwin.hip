@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     const uint64_t safe_end = g.in_bytes - lo;
     const uint16_t *S = S_all + (size_t)c * kSStrideF + kSPadF;
     const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
-    uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t cm = chunk_of(g, c); // (a launch over a list of chunks: input, tokens and meta are the listed chunk's, the sorted buckets are slot c's)
+    uint32_t *tok = tokens + (size_t)cm * kChunkMax;
     const uint32_t base = chunk_base(g, c), npos = n >= 3 ? n - 2 : 0;
     uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
     const uint32_t ring_a = fw_lds_base(fw_lds), stg_a = fw_lds_base(fw_lds + kFwOffStg) + lane * kFwStgStride;
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     FW_END();
     token_top(n); // the loop top that finds the input at its end (deflate.c:1459-1466): the slide may still happen here
     if (off != 0 && block_start + base < kWSize) nostore |= 1u << nblk; // the final block (its emission happens in the Huffman stage)
-    if (lane == 0) { meta[c].ntok = ntok; meta[c].nostore = nostore; meta[c].in_bytes = n; }
+    if (lane == 0) { meta[cm].ntok = ntok; meta[cm].nostore = nostore; meta[cm].in_bytes = n; }
 }
 
 // the levels' own parameters only (deflate.c:137-149): a tuned stream goes to the lane-per-chunk loop

@@ -124,15 +124,25 @@ struct SerialLzT {
     }
 };
 
+// `hand_on` (deflate_fast only): this loop's time goes with the tokens of a chunk -- each one a chain of dependent memory accesses -- and a launch takes
+// as long as its slowest chunks: 4 GiB of the Silesia-mix take 377 ms at level 1, 232 ms without the 5 % of its chunks that do not compress (65 000
+// literals each), which the wave-per-chunk kernel does in 3.5 ms apiece (scripts/serial_classes.py).  So a lane that finds, every 4096 bytes, more than
+// seven tokens per ten bytes behind it gives the chunk up (returns false, the kernel marks it kHandedOn) and the engine runs zgpu_lz_fastwin.hip
+// over the chunks given up.  Either kernel's tokens are the reference's, so who compresses a chunk shows in the time only.
 template <bool kSlow, bool kGeo>
-__device__ void lz_serial_chunk(SerialLzT<kGeo> &s)
+__device__ bool lz_serial_chunk(SerialLzT<kGeo> &s, bool hand_on)
 {
     const uint32_t n = s.n, maxd = s.maxdist();
     uint32_t room = 2 * s.wsize() - s.base, buffered = n < room ? n : room; // first fill_window (deflate.c:1275,1342)
     uint32_t p = s.start, match_len = kMinMatch - 1, prev_len = 0, mstart = 0, prev_match = 0, hh = 0;
     bool pending = false;
     for (uint32_t q = 0; q + kMinMatch <= s.start; q++) s.insert(q); // all dictionary strings but the last two (deflate.c:345-351)
+    uint32_t next_check = 4096;
     for (;;) {
+        if (!kSlow && hand_on && p >= next_check) {
+            if ((uint64_t)s.ntok * 10 > (uint64_t)p * 7) return false;
+            next_check += 4096;
+        }
         if (buffered - p < kMinLookahead) { buffered = s.fill(p, buffered); if (n == p) break; }
         uint32_t look = n - p;
         if (look >= kMinMatch) hh = s.insert(p);
@@ -177,12 +187,13 @@ __device__ void lz_serial_chunk(SerialLzT<kGeo> &s)
     // the block, that block -- all its tokens -- is the final one, with no empty block behind it
     if (kSlow && pending && s.emit(tok_lit(s.in[p - 1]))) s.nostore |= kFullFinalBlock;
     s.cut_block(p); // the final block (its emission happens in the Huffman stage)
+    return true;
 }
 
 // grid: one lane per chunk of the batch.  tables: per chunk head[] then prev[], u16 (head zeroed by the host side): 2 x 32768 entries, or
 // (kGeo) 2^hash_bits + 2^w_bits at a stride of kGeoTableEntries.
 template <bool kGeo>
-__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits)
+__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits, uint32_t hand_on)
 {
     // `lanes` chunks per wave: a wave's step takes as long as its slowest lane's memory access, and fewer lanes per wave
     // means more waves to overlap those waits (the vector work per step is next to nothing)
@@ -205,11 +216,11 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
     }
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
-    if (cfg.slow) lz_serial_chunk<true, kGeo>(s); else lz_serial_chunk<false, kGeo>(s);
-    meta[c].ntok = s.ntok; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
+    const bool done = cfg.slow ? lz_serial_chunk<true, kGeo>(s, false) : lz_serial_chunk<false, kGeo>(s, hand_on != 0 && s.start == 0);
+    meta[c].ntok = done ? s.ntok : kHandedOn; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
 }
 
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits)
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on)
 {
     // chunks per wave: measured best (MI355X, level 1) where the launch has about 4096 waves -- 16 per CU; 64 chunks per wave
     // (1024 waves at 4 GiB) is 30 % slower, 8192 waves again slower.  ZGPU_SERIAL_LANES overrides.
@@ -217,8 +228,8 @@ void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32
     if (forced < 0) { const char *e = getenv("ZGPU_SERIAL_LANES"); forced = e ? atoi(e) : 0; if (forced < 0 || forced > 64) forced = 0; }
     uint32_t lanes = (uint32_t)forced;
     if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
-    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits);
-    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits);
+    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, 0u);
+    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, hand_on ? 1u : 0u);
 }
 
 } // namespace zgpu

@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
         uint64_t a = 1, b = n;
         for (uint32_t w = 0; w < kS3Waves; w++) { a += ad1[w]; b += ad2[w] % 65521u; }
         for (uint32_t p = npos; p < n; p++) { a += src[p]; b += (uint64_t)(n - p) * src[p]; }
-        meta[c].adler_a = (uint32_t)(a % 65521u); meta[c].adler_b = (uint32_t)(b % 65521u); meta[c].in_bytes = n;
+        ChunkMeta &mc = meta[chunk_of(g, c)];
+        mc.adler_a = (uint32_t)(a % 65521u); mc.adler_b = (uint32_t)(b % 65521u); mc.in_bytes = n;
     }
     S3_STOP(1);
 

@@ -266,6 +266,18 @@ void launch_crc(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)
     hipLaunchKernelGGL(crc_kernel, dim3(g.nchunks), dim3(256), 0, st, g, meta);
 }
 
+// the batch's chunks the lane-per-chunk loop has handed on (ChunkMeta::ntok == kHandedOn), as a list for a launch of the wave-per-chunk kernel (any order)
+__global__ void __launch_bounds__(256) collect_handed_on_kernel(const ChunkMeta *__restrict__ meta, uint32_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ count)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n && meta[c].ntok == kHandedOn) list[atomicAdd(count, 1u)] = c;
+}
+void launch_collect_handed_on(const ChunkMeta *meta, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t st)
+{
+    hipMemsetAsync(count, 0, 4, st);
+    hipLaunchKernelGGL(collect_handed_on_kernel, dim3((n + 255) / 256), dim3(256), 0, st, meta, n, list, count);
+}
+
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st)
 {
     hipLaunchKernelGGL(adler_kernel, dim3(g.nchunks), dim3(256), 0, st, g, meta);
