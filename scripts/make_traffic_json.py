@@ -44,8 +44,9 @@ out = {
     "deflate-L9-silesia-mix-4gib-match": entry("r03_L9_4gib_summary.txt", "walk_kernel<true>",
         "the same kernel with 4096-deep chains: bodies 67 % of a wave's cycles, 44 candidate steps per byte (profiles/r03_walk_phases_levels_4_6_9.txt)"),
     "deflate-L1-silesia-mix-4gib-lz_serial": entry("r03_L1_4gib_lz_serial_summary.txt", "lz_serial_kernel",
-        "request rate of the memory system behind L2: one lane per chunk, 65 536 chains of dependent scattered reads (head, candidate bytes, prev) in flight "
-        "(profiles/r02_random_sectors.txt: 48 G requests/s is the cap); the wave-per-chunk kernel that serves calls below 2.25 GiB is issue-bound instead (one wave per SIMD)"),
+        "latency of the slowest chunks' chains of dependent scattered reads (head, candidate bytes, prev): one lane per chunk, a launch lasts as long as the chunk with the most "
+        "tokens; the 5 % of chunks that do not compress go to the wave-per-chunk kernel after 4 KiB (377 -> 232 ms, profiles/r03_serial_loop_by_class.txt, r03_hand_on_levels_1_3.txt); "
+        "that kernel, which serves launches below 1.25 GiB alone, is issue-bound instead (one wave per SIMD)"),
     "deflate-L1-silesia-mix-1gib-match": entry("r03_L1_fastwin_1gib_summary.txt", "fastwin_kernel<4, 8>",
         "instruction issue of a lone wave per SIMD (one instruction every 5-6 cycles), three chunks per CU (47 KiB of LDS each): 12 000 cycles per 64-position window, "
         "evaluation 31 % / scalar walk 49 % (profiles/r03_fastwin_phases.txt)"),

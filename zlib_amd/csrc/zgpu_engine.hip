@@ -229,8 +229,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         // implementation for the parity tests and for ZGPU_LZ_DEFAULT=5: it asks memory four times less often and is no faster
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env == ZGPU_LZ_FAST) impl = ZGPU_LZ_FAST;
         // levels 1-3: a wave per chunk, window and chain bits in LDS (zgpu_lz_fastwin.hip) -- 5 ms a chunk whatever the size of the call, three chunks per
-        // CU; the lane-per-chunk loop takes 28 ms a chunk and needs tens of thousands of them in flight.  Measured crossovers (chunks per call, 4 GiB =
-        // 65536): level 1 about 40000, level 2 about 28000, level 3 (32 candidates a lane) about 4000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
+        // CU; the lane-per-chunk loop takes 28 ms a chunk and needs tens of thousands of them in flight.  Measured crossovers against the loop with its
+        // hand-on (chunks per launch, 4 GiB = 65536; profiles/r03_crossover_levels_1_3.txt): level 1 about 20000, level 2 about 24000, level 3 (32
+        // candidates a lane) about 6000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) {
             const uint64_t cs0 = p->chunk_size ? p->chunk_size : kChunkMax;
             uint64_t nch0 = d_seg ? nseg : (in_bytes + cs0 - 1) / cs0;
@@ -238,7 +239,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
                 const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 16384) : env_u32("ZGPU_BATCH_CHUNKS", 65536);
                 if (per_launch && nch0 > per_launch) nch0 = per_launch;
             }
-            const uint64_t upto = cfg.chain == 4 ? 36864 : cfg.chain == 8 ? 24576 : 4096;
+            const uint64_t upto = cfg.chain == 4 ? 20480 : cfg.chain == 8 ? 24576 : 6144;
             const char *ho = getenv("ZGPU_HAND_ON"); // 0: the loop keeps every chunk (A/B runs); 2: the loop + hand-on whatever the size of the call (tests)
             if (ho && ho[0] == '2' && auto_env == 0) hand_on = true;
             else if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;
