@@ -1,4 +1,4 @@
-"""Which chunks hold the lane-per-chunk loop back at level 1: the Silesia-mix without one class of segments at a time (4 GiB generated, rows of 1 MiB)."""
+"""Which chunks hold the lane-per-chunk loop back (level = argv[1], default 1): the Silesia-mix without one class of segments at a time (4 GiB generated, rows of 1 MiB)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, zlib_amd
@@ -13,7 +13,9 @@ cls = torch.tensor([slots[i % 20] for i in range(rows.shape[0])], device="cuda")
 names = ["text", "markup", "logs", "code", "numeric", "lowbin", "random"]
 cap = e.L.zgpu_deflate_bound(n * 65536, 65536)
 dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
-def run(t, impl, lvl=1):
+LVL = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+def run(t, impl, lvl=None):
+    lvl = LVL if lvl is None else lvl
     nb = t.numel()
     best = 1e9
     for _ in range(2):
