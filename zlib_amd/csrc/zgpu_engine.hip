@@ -157,7 +157,7 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
     }
     if (serial && !geo && batch > e->tables_cap) {
         hipFree(e->tables); e->tables = nullptr; e->tables_cap = 0;
-        if ((rc = dev_alloc(e, &e->tables, (size_t)batch * (kHashSize + kWSize)))) return rc;
+        if ((rc = dev_alloc(e, &e->tables, (size_t)batch * kSerialTableEntries))) return rc;
         e->tables_cap = batch;
     }
     if (!serial && batch > e->par_cap) {
@@ -275,7 +275,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)(kHashSize + kWSize) * 2 + (hand_on ? lz_sorted_workspace_bytes(1) : 0) : lz_sorted_workspace_bytes(1));
+        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)kSerialTableEntries * 2 + (hand_on ? lz_sorted_workspace_bytes(1) : 0) : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
@@ -380,7 +380,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
                 ZGPU_HIP_CHECK(hipMemset2DAsync(e->geo_tables, (size_t)kGeoTableEntries * 2, 0, (size_t)2 << cfg.hash_bits, nb, st)); // head[] only
                 launch_lz_serial(g, cfg, e->geo_tables, e->tokens, e->meta, st, e->geo_nostore);
             } else {
-                ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)(kHashSize + kWSize) * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
+                ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)kSerialTableEntries * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
                 launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr, hand_on);
             }
             if (hand_on) { // the chunks the loop gave up, as a list, through the wave-per-chunk kernel (their number decides the launch: one word comes home)

@@ -27,7 +27,8 @@ template <bool kGeo>
 struct SerialLzT {
     const uint8_t *__restrict__ in;
     uint32_t n, base, off, start; // start: a preset dictionary occupies positions [0, start) (deflate.c:315-354)
-    uint16_t *head, *prev;
+    uint16_t *head;
+    uint64_t *link; // per window position: prev[] entry (low 16 bits) and the six bytes of the string that starts there (see insert)
     uint32_t *tok;
     uint32_t ntok, blk_tok0, nblk, nostore, block_start;
     LevelCfg cfg;
@@ -43,15 +44,24 @@ struct SerialLzT {
     // derived window index of a table entry; <= 0 means NIL
     __device__ int entry_w(uint32_t e) const { return e == 0 ? 0 : (int)(e - 1 + base) - (int)off; }
 
+    // the first eight bytes of the string at p (zeros behind the end of the chunk)
+    __device__ uint64_t bytes8(uint32_t p) const
+    {
+        if (p + 8 <= n) return reinterpret_cast<const U64s *>(in + p)->v;
+        uint64_t v = 0;
+        for (uint32_t k = 0; p + k < n && k < 8; k++) v |= (uint64_t)in[p + k] << (8 * k);
+        return v;
+    }
     __device__ uint32_t insert(uint32_t p)
     {
-        // (every global load of this lane-per-chunk loop is a dependent round trip of several hundred ns even when it hits:
-        // one unaligned dword instead of three byte loads, eight bytes per comparison step instead of one)
-        uint32_t h;
-        if (p + 4 <= n) { const uint32_t v = reinterpret_cast<const U32s *>(in + p)->v; h = hash(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u); }
-        else h = hash(in[p], in[p + 1], in[p + 2]);
+        // (every global load of this lane-per-chunk loop is a dependent round trip of several hundred ns even when it hits, and pulls a whole line
+        // for two bytes: 870 GB crossed the fabric per 4 GiB launch at level 1.  So a chain entry holds, beside the reference's prev[] value, the first
+        // six bytes of its string: longest_match's walk takes ONE line per candidate -- link and bytes -- instead of one of prev[] and one of the input,
+        // and goes to the input only for a candidate that agrees in all six.  The entries are written in position order, eight to a line.)
+        const uint64_t v = bytes8(p);
+        const uint32_t h = hash((uint32_t)v & 255u, (uint32_t)(v >> 8) & 255u, (uint32_t)(v >> 16) & 255u);
         uint32_t old = head[h];
-        prev[(p + base) & wmask()] = (uint16_t)old;
+        link[(p + base) & wmask()] = (uint64_t)(uint16_t)old | (v << 16);
         head[h] = (uint16_t)(p + 1);
         return old;
     }
@@ -90,23 +100,27 @@ struct SerialLzT {
         if (nice > look) nice = look;
         uint32_t e = e0;
         const uint8_t *scan = in + p;
+        const uint64_t scan6 = bytes8(p) << 16; // (the same six bytes, where a chain entry has them)
         do {
-            uint32_t q = e - 1;
-            const uint8_t *m = in + q;
-            // quick reject on the byte that would extend the best match so far (deflate.c:1121-1124); with a short best match the
-            // first eight bytes of the comparison cost the same one round trip and say more
-            if (best < cap && (best < 8 || m[best] == scan[best])) {
-                uint32_t l = 0;
-                while (l + 8 <= cap) { // (cap <= look: both reads stay inside the chunk)
-                    const uint64_t x = reinterpret_cast<const U64s *>(m + l)->v ^ reinterpret_cast<const U64s *>(scan + l)->v;
-                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; goto compared; }
-                    l += 8;
+            const uint32_t q = e - 1;
+            const uint64_t ent = link[(q + base) & wmask()];
+            const uint64_t x6 = (ent ^ scan6) >> 16;
+            uint32_t l = x6 ? (uint32_t)__builtin_ctzll(x6) >> 3 : 6u;
+            if (l == 6 && cap > 6 && best < cap) { // all six agree: the rest from the input (a candidate no longer than the best so far changes nothing, deflate.c:1121-1124)
+                const uint8_t *m = in + q;
+                if (best < 8 || m[best] == scan[best]) {
+                    while (l + 8 <= cap) { // (cap <= look: both reads stay inside the chunk)
+                        const uint64_t x = reinterpret_cast<const U64s *>(m + l)->v ^ reinterpret_cast<const U64s *>(scan + l)->v;
+                        if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; goto compared; }
+                        l += 8;
+                    }
+                    while (l < cap && m[l] == scan[l]) l++;
                 }
-                while (l < cap && m[l] == scan[l]) l++;
-            compared:
-                if (l > best) { mstart = q; best = l; if (l >= nice) break; }
             }
-            e = prev[(q + base) & wmask()];
+        compared:
+            if (l > cap) l = cap;
+            if (l > best) { mstart = q; best = l; if (l >= nice) break; }
+            e = (uint32_t)(uint16_t)ent;
             if (e == 0 || entry_w(e) <= limit) break;
         } while (--chain != 0);
         return best <= look ? best : look;
@@ -190,8 +204,8 @@ __device__ bool lz_serial_chunk(SerialLzT<kGeo> &s, bool hand_on)
     return true;
 }
 
-// grid: one lane per chunk of the batch.  tables: per chunk head[] then prev[], u16 (head zeroed by the host side): 2 x 32768 entries, or
-// (kGeo) 2^hash_bits + 2^w_bits at a stride of kGeoTableEntries.
+// grid: one lane per chunk of the batch.  tables: per chunk head[] (u16, zeroed by the host side) then the chain entries (u64, one per window position):
+// 32768 + 4 x 32768 u16 units, or (kGeo) 2^hash_bits + 4 x 2^w_bits at a stride of kGeoTableEntries.
 template <bool kGeo>
 __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits, uint32_t hand_on)
 {
@@ -209,10 +223,10 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
         s.g_wsize = 1u << cfg.w_bits; s.g_hmask = (1u << cfg.hash_bits) - 1u; s.g_hshift = (cfg.hash_bits + kMinMatch - 1) / kMinMatch; s.g_btok = g.block_tokens;
         s.g_nostore = nostore_bits + (size_t)c * kGeoNostoreWords;
         for (uint32_t i = 0; i < kGeoNostoreWords; i++) s.g_nostore[i] = 0;
-        s.head = tables + (size_t)c * kGeoTableEntries; s.prev = s.head + (1u << cfg.hash_bits);
+        s.head = tables + (size_t)c * kGeoTableEntries; s.link = reinterpret_cast<uint64_t *>(s.head + (1u << cfg.hash_bits));
     } else {
         s.g_wsize = kWSize; s.g_hmask = kHashMask; s.g_hshift = 5; s.g_btok = kBlockTokens; s.g_nostore = nullptr;
-        s.head = tables + (size_t)c * (kHashSize + kWSize); s.prev = s.head + kHashSize;
+        s.head = tables + (size_t)c * kSerialTableEntries; s.link = reinterpret_cast<uint64_t *>(s.head + kHashSize);
     }
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
