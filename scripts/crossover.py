@@ -18,7 +18,7 @@ def run(n, lvl, impl, env):
         e.deflate_device(src.data_ptr(), n * 65536, lvl, dst.data_ptr(), cap, flags=gpu.F_FINAL, lz_impl=impl)
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     return best * 1e3
-for lvl in (1, 2, 3):
-    for n in (4096, 8192, 16384, 24576, 32768, 49152, 65536):
+for lvl in [int(x) for x in os.environ.get("LEVELS", "1,2,3").split(",")]:
+    for n in [int(x) for x in os.environ.get("SIZES", "4096,8192,16384,24576,32768,49152,65536").split(",")]:
         a = run(n, lvl, gpu.LZ_FASTWIN, None); b = run(n, lvl, gpu.LZ_AUTO, "2"); c = run(n, lvl, gpu.LZ_SERIAL, None)
         print("level %d  %5d chunks: wave kernel %7.1f ms   loop + hand-on %7.1f ms   loop alone %7.1f ms" % (lvl, n, a, b, c), flush=True)

@@ -7,8 +7,8 @@ n = 16384 * 4
 src = torch.empty(n * 65536, dtype=torch.uint8, device="cuda")
 e.corpus_fill_device(0, 0x5EED5117, 0, n, src.data_ptr())
 h = src.cpu().numpy()
-for lvl in (1, 6):
-    for impl in ((gpu.LZ_AUTO, gpu.LZ_SERIAL, gpu.LZ_FASTWIN) if lvl == 1 else (gpu.LZ_AUTO,)):
+for lvl in (1, 2, 3, 6):
+    for impl in (gpu.LZ_AUTO,):
         for rep in range(2):
             e.profile(True)
             t = time.perf_counter(); z = e.deflate_host(h, lvl, lz_impl=impl); dt = time.perf_counter() - t

@@ -230,16 +230,16 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && auto_env == ZGPU_LZ_FAST) impl = ZGPU_LZ_FAST;
         // levels 1-3: a wave per chunk, window and chain bits in LDS (zgpu_lz_fastwin.hip) -- 5 ms a chunk whatever the size of the call, three chunks per
         // CU; the lane-per-chunk loop takes 28 ms a chunk and needs tens of thousands of them in flight.  Measured crossovers against the loop with its
-        // hand-on (chunks per launch, 4 GiB = 65536; profiles/r03_crossover_levels_1_3.txt): level 1 about 20000, level 2 about 24000, level 3 (32
-        // candidates a lane) about 6000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
+        // hand-on (chunks per launch, 4 GiB = 65536; profiles/r03_crossover_levels_1_3.txt): levels 1 and 2 about 16000 -- a host batch --, level 3 (32
+        // candidates a lane) about 3000.  ZGPU_LZ_DEFAULT=1 keeps the loop, =6 the waves.
         if (!cfg.slow && lz_parallel_available() && walk_ok && !skip0 && lz_fastwin_serves(cfg) && auto_env != ZGPU_LZ_FAST && auto_env != ZGPU_LZ_SERIAL) {
             const uint64_t cs0 = p->chunk_size ? p->chunk_size : kChunkMax;
             uint64_t nch0 = d_seg ? nseg : (in_bytes + cs0 - 1) / cs0;
             { // what counts is the chunks of ONE launch: host input goes batch by batch (see below), and every batch of the loop would pay its latency again
-                const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 16384) : env_u32("ZGPU_BATCH_CHUNKS", 65536);
+                const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 65536) : env_u32("ZGPU_BATCH_CHUNKS", 65536); // (levels 1-3: see host_batch below)
                 if (per_launch && nch0 > per_launch) nch0 = per_launch;
             }
-            const uint64_t upto = cfg.chain == 4 ? 20480 : cfg.chain == 8 ? 24576 : 6144;
+            const uint64_t upto = cfg.chain == 4 ? 16384 : cfg.chain == 8 ? 16384 : 3072;
             const char *ho = getenv("ZGPU_HAND_ON"); // 0: the loop keeps every chunk (A/B runs); 2: the loop + hand-on whatever the size of the call (tests)
             if (ho && ho[0] == '2' && auto_env == 0) hand_on = true;
             else if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;
@@ -271,7 +271,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // host input: the copy of batch k+1 runs under the kernels of batch k.  Batches must stay large: the block-construction and sort kernels are
     // latency-bound and need every workgroup slot of the chip filled several times over (2048 chunks per launch: 2.2x the time per byte of
     // 65536, rocprofv3 timeline of scripts/host_trace.py); the copy moves 57 GB/s and is over long before the kernels are
-    const uint32_t host_batch = env_u32("ZGPU_HOST_BATCH", 16384); // (A/B runs; measured at 4 GiB: 8192 184.8 ms, 16384 176.3, 32768 178.5)
+    // (levels 1-3: both of their kernels want the launch as large as it gets -- the loop's time hardly grows with the chunks, 170 ms for 32768 and 245 for
+    // 65536 at level 1 -- and take far longer than the copy they would hide, so host input is not cut up there)
+    const uint32_t host_batch = env_u32("ZGPU_HOST_BATCH", cfg.slow ? 16384 : 65536); // (A/B runs; measured at 4 GiB, level 6: 8192 184.8 ms, 16384 176.3, 32768 178.5)
     if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
@@ -329,7 +331,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     // before it -- and what the short launches cost the latency-bound kernels (see above) is less than what the shorter wait saves
     // (1 GiB: 58.3 -> 55.5 ms; profiles/r02_host_batches_ab.txt)
     const uint32_t first_env = env_u32("ZGPU_FIRST_BATCH", 2048); // (chunks; 0: all batches alike, for A/B runs)
-    const uint32_t first = (h_src && first_env && batch >= 2 * first_env && nchunks > first_env) ? first_env : batch;
+    const uint32_t first = (h_src && cfg.slow && first_env && batch >= 2 * first_env && nchunks > first_env) ? first_env : batch; // (levels 1-3: no ramp either)
     auto next_step = [batch](uint32_t s) { return s >= batch / 2 ? batch : s * 2; };
     size_t nbatches = 0;
     for (uint64_t c0 = 0, step = first; c0 < nchunks; c0 += step, step = next_step((uint32_t)step)) nbatches++;
