@@ -16,8 +16,8 @@ constexpr uint32_t kMaxDist = kWSize - kMinLookahead; // 32506
 constexpr uint32_t kTooFar = 4096;
 constexpr uint32_t kChunkMax = 65536;
 constexpr uint32_t kBlockTokens = 16383;       // lit_bufsize-1: a block is cut after this many tokens
-constexpr uint32_t kSerialTableEntries = 32768 + 4 * 32768; // u16 units per chunk of the lane-per-chunk loop's tables: head[] (u16) + one u64 chain entry per window position
-constexpr uint32_t kGeoTableEntries = 65536 + 4 * 32768;   // the same at memLevel 9 / windowBits 15
+constexpr uint32_t kSerialTableEntries = 32768 + 32768; // uint4 entries per chunk of the lane-per-chunk loop's tables: one per hash bucket, one per window position (1 MiB)
+constexpr uint32_t kGeoTableEntries = 65536 + 32768;   // the same at memLevel 9 / windowBits 15
 constexpr uint32_t kGeoNostoreWords = 18;     // memLevel 1: 127 tokens a block, up to 517 blocks in a chunk
 constexpr uint32_t kGeoSlotStride = 65536 + 8192 + 1024 + 64 + 5 * 32 * kGeoNostoreWords + 448; // deflateBound's arithmetic (deflate.c:513-515) for a chunk whose blocks may not be stored, + a header per block
 constexpr uint32_t kMaxBlocks = 6;

@@ -14,7 +14,7 @@ namespace zgpu {
 struct RunStateHost { uint64_t out_total, in_total, ntokens; uint32_t adler_a, adler_b, data_type, overflow, crc, pad; };
 
 // kernels (other translation units)
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on = false);
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint4 *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on, uint32_t tag);
 void launch_collect_handed_on(const ChunkMeta *meta, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t st);
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees);
 void launch_adler(const ChunkGeom &g, ChunkMeta *meta, hipStream_t st);
@@ -52,14 +52,15 @@ struct zgpu_engine {
     uint32_t *tokens = nullptr;
     zgpu::ChunkMeta *meta = nullptr;
     uint8_t *slots = nullptr;
-    uint16_t *tables = nullptr;  // serial LZ only
+    uint4 *tables = nullptr;     // serial LZ only: zeroed when allocated, after that `serial_tag` tells one launch's buckets from another's (SerialLzT::insert)
+    uint32_t serial_tag = 0;
     uint32_t tables_cap = 0;
     void *par_ws = nullptr;      // parallel LZ only
     int tuned = 0; uint32_t tune[4] = {0, 0, 0, 0}; // zgpu_deflate_set_tuning: good, lazy, nice, chain instead of the level's
     uint64_t handed_on = 0; // (diagnostic: chunks handed on since the engine was made)
     uint32_t *hand_list = nullptr; uint32_t hand_cap = 0; // chunks the lane-per-chunk loop handed on: [0] their number, [1..] their indices in the batch
     int geo_w = 15, geo_m = 8;   // zgpu_deflate_set_geometry: deflateInit2's windowBits and memLevel
-    uint8_t *geo_slots = nullptr; uint16_t *geo_tables = nullptr; uint32_t *geo_nostore = nullptr; uint32_t geo_cap = 0; // the workspace of a non-default geometry
+    uint8_t *geo_slots = nullptr; uint4 *geo_tables = nullptr; uint32_t *geo_nostore = nullptr; uint32_t geo_cap = 0; // the workspace of a non-default geometry
     int exact_sort = 0;          // sticky: the fast sort's self-check failed once on this engine (zgpu_lz_sorted.hip, pass V)
     uint32_t par_cap = 0;
     uint64_t *offsets = nullptr; // nchunks+1 segment offsets of the current call
@@ -145,6 +146,8 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
         hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); e->geo_slots = nullptr; e->geo_tables = nullptr; e->geo_nostore = nullptr; e->geo_cap = 0;
         if ((rc = dev_alloc(e, &e->geo_slots, (size_t)batch * kGeoSlotStride))) return rc;
         if ((rc = dev_alloc(e, &e->geo_tables, (size_t)batch * kGeoTableEntries))) return rc;
+        ZGPU_HIP_CHECK(hipMemsetAsync(e->geo_tables, 0, (size_t)batch * kGeoTableEntries * sizeof(uint4), e->stream));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
         if ((rc = dev_alloc(e, &e->geo_nostore, (size_t)batch * kGeoNostoreWords))) return rc;
         e->geo_cap = batch;
     }
@@ -158,6 +161,8 @@ static int ensure_deflate_ws(zgpu_engine *e, uint32_t batch, bool serial, uint64
     if (serial && !geo && batch > e->tables_cap) {
         hipFree(e->tables); e->tables = nullptr; e->tables_cap = 0;
         if ((rc = dev_alloc(e, &e->tables, (size_t)batch * kSerialTableEntries))) return rc;
+        ZGPU_HIP_CHECK(hipMemsetAsync(e->tables, 0, (size_t)batch * kSerialTableEntries * sizeof(uint4), e->stream));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
         e->tables_cap = batch;
     }
     if (!serial && batch > e->par_cap) {
@@ -277,7 +282,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     if (h_src && batch_max > host_batch) batch_max = host_batch ? host_batch : 16384;
     {
         size_t free_b = 0, total_b = 0;
-        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * 2 : serial ? (size_t)kSerialTableEntries * 2 + (hand_on ? lz_sorted_workspace_bytes(1) : 0) : lz_sorted_workspace_bytes(1));
+        const size_t per_chunk = (size_t)kChunkMax * 4 + kSlotStride + (geo ? (size_t)kGeoSlotStride + (size_t)kGeoTableEntries * sizeof(uint4) : serial ? (size_t)kSerialTableEntries * sizeof(uint4) + (hand_on ? lz_sorted_workspace_bytes(1) / 4 : 0) : lz_sorted_workspace_bytes(1));
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = (size_t)e->batch_cap * per_chunk; // what this engine already owns can be reused
             const size_t budget = (free_b + held) / 10 * 6;
@@ -289,8 +294,11 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
     const uint32_t batch = (uint32_t)(nchunks < batch_max ? nchunks : batch_max);
     int rc = ensure_deflate_ws(e, batch, serial, nchunks, geo);
     if (rc) return rc;
+    uint32_t hand_piece = 0;
     if (hand_on) {
-        if ((rc = ensure_deflate_ws(e, batch, false, nchunks))) return rc; // the sorted buckets' workspace as well (every chunk may be handed on)
+        hand_piece = batch / 4 < 4096 ? (batch < 4096 ? batch : 4096) : batch / 4; // the sorted buckets' workspace: for a quarter of the batch at a time
+        if ((rc = ensure_deflate_ws(e, hand_piece, false, nchunks))) return rc;
+        if (e->par_cap > hand_piece) hand_piece = e->par_cap < batch ? e->par_cap : batch; // (an earlier call has left more)
         if (batch > e->hand_cap) {
             hipFree(e->hand_list); e->hand_list = nullptr; e->hand_cap = 0;
             if ((rc = dev_alloc(e, &e->hand_list, (size_t)batch + 1))) return rc;
@@ -378,20 +386,21 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
         bool adler_done = false;
         if (serial) {
             StageTimer t(e, st, ZGPU_STAGE_LZ_SERIAL);
-            if (geo) {
-                ZGPU_HIP_CHECK(hipMemset2DAsync(e->geo_tables, (size_t)kGeoTableEntries * 2, 0, (size_t)2 << cfg.hash_bits, nb, st)); // head[] only
-                launch_lz_serial(g, cfg, e->geo_tables, e->tokens, e->meta, st, e->geo_nostore);
-            } else {
-                ZGPU_HIP_CHECK(hipMemset2DAsync(e->tables, (size_t)kSerialTableEntries * 2, 0, (size_t)kHashSize * 2, nb, st)); // head[] only
-                launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr, hand_on);
+            // (a tag that these tables have not seen: 0 is what fresh tables hold; should the counter ever wrap, they are zeroed again)
+            if (++e->serial_tag == 0) {
+                if (e->tables) ZGPU_HIP_CHECK(hipMemsetAsync(e->tables, 0, (size_t)e->tables_cap * kSerialTableEntries * sizeof(uint4), st));
+                if (e->geo_tables) ZGPU_HIP_CHECK(hipMemsetAsync(e->geo_tables, 0, (size_t)e->geo_cap * kGeoTableEntries * sizeof(uint4), st));
+                e->serial_tag = 1;
             }
+            if (geo) launch_lz_serial(g, cfg, e->geo_tables, e->tokens, e->meta, st, e->geo_nostore, false, e->serial_tag);
+            else launch_lz_serial(g, cfg, e->tables, e->tokens, e->meta, st, nullptr, hand_on, e->serial_tag);
             if (hand_on) { // the chunks the loop gave up, as a list, through the wave-per-chunk kernel (their number decides the launch: one word comes home)
                 launch_collect_handed_on(e->meta, nb, e->hand_list + 1, e->hand_list, st);
                 uint32_t handed = 0;
                 ZGPU_HIP_CHECK(hipMemcpyAsync(&handed, e->hand_list, 4, hipMemcpyDeviceToHost, st));
                 ZGPU_HIP_CHECK(hipStreamSynchronize(st));
-                if (handed) {
-                    ChunkGeom gl = g; gl.nchunks = handed; gl.chunk_map = e->hand_list + 1;
+                for (uint32_t at = 0; at < handed; at += hand_piece) {
+                    ChunkGeom gl = g; gl.nchunks = handed - at < hand_piece ? handed - at : hand_piece; gl.chunk_map = e->hand_list + 1 + at;
                     launch_lz_sorted(gl, cfg, e->par_ws, e->tokens, e->meta, st, e, e->exact_sort, 3);
                 }
                 e->handed_on += handed;

@@ -27,8 +27,11 @@ template <bool kGeo>
 struct SerialLzT {
     const uint8_t *__restrict__ in;
     uint32_t n, base, off, start; // start: a preset dictionary occupies positions [0, start) (deflate.c:315-354)
-    uint16_t *head;
-    uint64_t *link; // per window position: prev[] entry (low 16 bits) and the six bytes of the string that starts there (see insert)
+    // The tables (see insert): 16 bytes per hash bucket and 16 bytes per window position, each holding what the walk needs of TWO chain members.
+    uint4 *head;  // x: e1 | e2 << 16 (the bucket's newest position + 1, and that position's prev[] entry), y: the launch tag, z/w: e1's first six bytes
+    uint4 *link;  // per window position q: x,y = prev[q] (e2) | q's six bytes << 16; z,w = prev[e2] (e3) | e2's six bytes << 16
+    uint32_t tag; // a bucket whose tag is not this launch's is empty (the tables are zeroed once, when they are allocated; the tag counts launches)
+    uint32_t in_e2; uint64_t in_pfx; // what insert() found in the bucket beside the position it returns: that position's prev[] entry and six bytes
     uint32_t *tok;
     uint32_t ntok, blk_tok0, nblk, nostore, block_start;
     LevelCfg cfg;
@@ -54,16 +57,24 @@ struct SerialLzT {
     }
     __device__ uint32_t insert(uint32_t p)
     {
-        // (every global load of this lane-per-chunk loop is a dependent round trip of several hundred ns even when it hits, and pulls a whole line
-        // for two bytes: 870 GB crossed the fabric per 4 GiB launch at level 1.  So a chain entry holds, beside the reference's prev[] value, the first
-        // six bytes of its string: longest_match's walk takes ONE line per candidate -- link and bytes -- instead of one of prev[] and one of the input,
-        // and goes to the input only for a candidate that agrees in all six.  The entries are written in position order, eight to a line.)
+        // Every global load of this lane-per-chunk loop is a dependent round trip of one to two microseconds under load, and pulls a whole line for the
+        // two bytes it wants: with head[] / prev[] as the reference has them 870 GB crossed the fabric per 4 GiB launch at level 1 -- 4 TB/s, what HBM gives
+        // for random lines -- so what counts is LINES PER TOKEN.  A bucket therefore holds, beside its newest position e1, that position's prev[] entry e2 and
+        // its first six bytes: the first candidate of a search is judged from the line that had to be read anyway.  A window position's entry holds its own
+        // prev[] entry and six bytes AND those of the position it links to: every line read during longest_match's walk serves two candidates, and the
+        // input itself is read only for a candidate that agrees in all six bytes.  (All of it is copies of values that never change once written: prev[q]
+        // and the bytes at q.  Entries are written in position order, four to a line.)
         const uint64_t v = bytes8(p);
         const uint32_t h = hash((uint32_t)v & 255u, (uint32_t)(v >> 8) & 255u, (uint32_t)(v >> 16) & 255u);
-        uint32_t old = head[h];
-        link[(p + base) & wmask()] = (uint64_t)(uint16_t)old | (v << 16);
-        head[h] = (uint16_t)(p + 1);
-        return old;
+        const uint4 b = head[h];
+        const bool live = b.y == tag;
+        const uint32_t e1 = live ? b.x & 0xffffu : 0u, e2 = (live && e1) ? b.x >> 16 : 0u;
+        const uint64_t pfx1 = ((uint64_t)b.w << 32 | b.z) & 0xffffffffffffull;
+        const uint64_t me = (uint64_t)e1 | (v << 16), nx = (uint64_t)e2 | (pfx1 << 16);
+        link[(p + base) & wmask()] = make_uint4((uint32_t)me, (uint32_t)(me >> 32), (uint32_t)nx, (uint32_t)(nx >> 32));
+        head[h] = make_uint4((p + 1) | (e1 << 16), tag, (uint32_t)v, (uint32_t)(v >> 32) & 0xffffu);
+        in_e2 = e2; in_pfx = pfx1;
+        return e1;
     }
 
     // the slide test of fill_window (deflate.c:1293); called wherever the reference calls fill_window
@@ -98,13 +109,15 @@ struct SerialLzT {
         uint32_t cap = look < kMaxMatch ? look : kMaxMatch;
         if (prev_length >= cfg.good) chain >>= 2;
         if (nice > look) nice = look;
-        uint32_t e = e0;
         const uint8_t *scan = in + p;
-        const uint64_t scan6 = bytes8(p) << 16; // (the same six bytes, where a chain entry has them)
-        do {
+        const uint64_t scan6 = bytes8(p) & 0xffffffffffffull;
+        // the candidate in hand: its position + 1, six bytes and prev[] entry; `ahead`: the same of the candidate it links to are known already
+        uint32_t e = e0, elink = in_e2, alink = 0;
+        uint64_t epfx = in_pfx, apfx = 0;
+        bool ahead = false;
+        for (;;) {
             const uint32_t q = e - 1;
-            const uint64_t ent = link[(q + base) & wmask()];
-            const uint64_t x6 = (ent ^ scan6) >> 16;
+            const uint64_t x6 = epfx ^ scan6;
             uint32_t l = x6 ? (uint32_t)__builtin_ctzll(x6) >> 3 : 6u;
             if (l == 6 && cap > 6 && best < cap) { // all six agree: the rest from the input (a candidate no longer than the best so far changes nothing, deflate.c:1121-1124)
                 const uint8_t *m = in + q;
@@ -120,9 +133,17 @@ struct SerialLzT {
         compared:
             if (l > cap) l = cap;
             if (l > best) { mstart = q; best = l; if (l >= nice) break; }
-            e = (uint32_t)(uint16_t)ent;
+            e = elink;
             if (e == 0 || entry_w(e) <= limit) break;
-        } while (--chain != 0);
+            if (--chain == 0) break;
+            if (ahead) { epfx = apfx; elink = alink; ahead = false; }
+            else {
+                const uint4 t = link[(e - 1 + base) & wmask()];
+                elink = t.x & 0xffffu; epfx = ((uint64_t)t.y << 16) | (t.x >> 16);
+                alink = t.z & 0xffffu; apfx = ((uint64_t)t.w << 16) | (t.z >> 16);
+                ahead = true;
+            }
+        }
         return best <= look ? best : look;
     }
     // longest_match_fast (deflate.c:1173-1228; reached with Z_RLE only in this build): the common prefix with the one candidate
@@ -204,10 +225,10 @@ __device__ bool lz_serial_chunk(SerialLzT<kGeo> &s, bool hand_on)
     return true;
 }
 
-// grid: one lane per chunk of the batch.  tables: per chunk head[] (u16, zeroed by the host side) then the chain entries (u64, one per window position):
-// 32768 + 4 x 32768 u16 units, or (kGeo) 2^hash_bits + 4 x 2^w_bits at a stride of kGeoTableEntries.
+// grid: one lane per chunk of the batch.  tables: per chunk 16 bytes per hash bucket, then 16 bytes per window position (SerialLzT::insert): 2 x 32768 uint4,
+// or (kGeo) 2^hash_bits + 2^w_bits at a stride of kGeoTableEntries.  Zeroed when allocated; `tag` (never 0, never repeated on these tables) marks this launch's buckets.
 template <bool kGeo>
-__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits, uint32_t hand_on)
+__global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg, uint4 *tables, uint32_t *tokens, ChunkMeta *meta, uint32_t lanes, uint32_t *nostore_bits, uint32_t hand_on, uint32_t tag)
 {
     // `lanes` chunks per wave: a wave's step takes as long as its slowest lane's memory access, and fewer lanes per wave
     // means more waves to overlap those waits (the vector work per step is next to nothing)
@@ -223,18 +244,19 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
         s.g_wsize = 1u << cfg.w_bits; s.g_hmask = (1u << cfg.hash_bits) - 1u; s.g_hshift = (cfg.hash_bits + kMinMatch - 1) / kMinMatch; s.g_btok = g.block_tokens;
         s.g_nostore = nostore_bits + (size_t)c * kGeoNostoreWords;
         for (uint32_t i = 0; i < kGeoNostoreWords; i++) s.g_nostore[i] = 0;
-        s.head = tables + (size_t)c * kGeoTableEntries; s.link = reinterpret_cast<uint64_t *>(s.head + (1u << cfg.hash_bits));
+        s.head = tables + (size_t)c * kGeoTableEntries; s.link = s.head + (1u << cfg.hash_bits);
     } else {
         s.g_wsize = kWSize; s.g_hmask = kHashMask; s.g_hshift = 5; s.g_btok = kBlockTokens; s.g_nostore = nullptr;
-        s.head = tables + (size_t)c * kSerialTableEntries; s.link = reinterpret_cast<uint64_t *>(s.head + kHashSize);
+        s.head = tables + (size_t)c * kSerialTableEntries; s.link = s.head + kHashSize;
     }
+    s.tag = tag; s.in_e2 = 0; s.in_pfx = 0;
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
     const bool done = cfg.slow ? lz_serial_chunk<true, kGeo>(s, false) : lz_serial_chunk<false, kGeo>(s, hand_on != 0 && s.start == 0);
     meta[c].ntok = done ? s.ntok : kHandedOn; meta[c].nostore = s.nostore; meta[c].in_bytes = s.n;
 }
 
-void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on)
+void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint4 *tables, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, uint32_t *nostore_bits, bool hand_on, uint32_t tag)
 {
     // chunks per wave: measured best (MI355X, level 1) where the launch has about 4096 waves -- 16 per CU; 64 chunks per wave
     // (1024 waves at 4 GiB) is 30 % slower, 8192 waves again slower.  ZGPU_SERIAL_LANES overrides.
@@ -242,8 +264,8 @@ void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint16_t *tables, uint32
     if (forced < 0) { const char *e = getenv("ZGPU_SERIAL_LANES"); forced = e ? atoi(e) : 0; if (forced < 0 || forced > 64) forced = 0; }
     uint32_t lanes = (uint32_t)forced;
     if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
-    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, 0u);
-    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, hand_on ? 1u : 0u);
+    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, 0u, tag);
+    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, hand_on ? 1u : 0u, tag);
 }
 
 } // namespace zgpu
