@@ -19,6 +19,8 @@ namespace zgpu {
 
 struct __attribute__((packed, aligned(1))) U32s { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U64s { uint64_t v; };
+struct __attribute__((packed, aligned(1))) U128s { uint4 v; };
+constexpr uint32_t kSerialWin = 128, kSerialWinStride = kSerialWin + 16; // bytes of input a lane keeps in LDS; the lanes' windows 144 bytes apart
 
 // kGeo: deflateInit2's windowBits / memLevel are not the default (deflate.c:222-297): window size, hash width and shift and the tokens of a block
 // are run-time values, the window may slide many times in a chunk (the derived index covers that: `off` grows by a window each time), and the
@@ -47,12 +49,29 @@ struct SerialLzT {
     // derived window index of a table entry; <= 0 means NIL
     __device__ int entry_w(uint32_t e) const { return e == 0 ? 0 : (int)(e - 1 + base) - (int)off; }
 
-    // the first eight bytes of the string at p (zeros behind the end of the chunk)
-    __device__ uint64_t bytes8(uint32_t p) const
+    // the first eight bytes of the string at p (zeros behind the end of the chunk).  They come from a window of the input in LDS, 128 bytes per lane, refilled
+    // every 64: the loop asks for them once per inserted position, and between two of a lane's steps the line they lie in has long left the caches (the
+    // other 8 000 lanes of the XCD pull three table lines per step through a 4 MiB L2), so every insert fetched its input line from the fabric again.
+    uint32_t win_lds, win_base; // LDS byte address of this lane's window; the chunk offset it starts at (0x80000000: nothing in it yet)
+    __device__ void win_fill(uint32_t p)
     {
-        if (p + 8 <= n) return reinterpret_cast<const U64s *>(in + p)->v;
-        uint64_t v = 0;
-        for (uint32_t k = 0; p + k < n && k < 8; k++) v |= (uint64_t)in[p + k] << (8 * k);
+        win_base = p & ~63u;
+#pragma unroll
+        for (uint32_t k = 0; k < kSerialWin / 16; k++) {
+            const uint32_t o = win_base + 16 * k;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o + 16 <= n) v = reinterpret_cast<const U128s *>(in + o)->v;
+            else if (o < n) { uint32_t w[4] = {0, 0, 0, 0}; for (uint32_t b = 0; o + b < n && b < 16; b++) w[b >> 2] |= (uint32_t)in[o + b] << (8 * (b & 3)); v = make_uint4(w[0], w[1], w[2], w[3]); }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>((uintptr_t)(win_lds + 16 * k)) = u32x4{v.x, v.y, v.z, v.w};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the window is this lane's alone; the reads below are asm and must stay behind these stores)
+    }
+    __device__ uint64_t bytes8(uint32_t p)
+    {
+        if (p - win_base > kSerialWin - 8) win_fill(p); // (also when p lies in front of the window, or nothing is in it: the difference wraps)
+        uint64_t v;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(win_lds + (p - win_base)) : "memory");
         return v;
     }
     __device__ uint32_t insert(uint32_t p)
@@ -102,7 +121,7 @@ struct SerialLzT {
     __device__ bool emit(uint32_t t) { tok[ntok++] = t; return ntok - blk_tok0 == btok(); }
 
     // longest_match; e0 is the table entry of the first candidate.  Returns the match length and sets mstart.
-    __device__ uint32_t longest(uint32_t p, uint32_t e0, uint32_t prev_length, uint32_t &mstart) const
+    __device__ uint32_t longest(uint32_t p, uint32_t e0, uint32_t prev_length, uint32_t &mstart)
     {
         uint32_t chain = cfg.chain, look = n - p, nice = cfg.nice, best = prev_length;
         int w = widx(p), limit = w > (int)maxdist() ? w - (int)maxdist() : 0;
@@ -249,6 +268,8 @@ __global__ void __launch_bounds__(64) lz_serial_kernel(ChunkGeom g, LevelCfg cfg
         s.g_wsize = kWSize; s.g_hmask = kHashMask; s.g_hshift = 5; s.g_btok = kBlockTokens; s.g_nostore = nullptr;
         s.head = tables + (size_t)c * kSerialTableEntries; s.link = s.head + kHashSize;
     }
+    extern __shared__ __attribute__((aligned(16))) uint8_t serial_win[];
+    s.win_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)serial_win + threadIdx.x * kSerialWinStride; s.win_base = 0x80000000u;
     s.tag = tag; s.in_e2 = 0; s.in_pfx = 0;
     s.tok = tokens + (size_t)c * kChunkMax;
     s.ntok = 0; s.blk_tok0 = 0; s.nblk = 0; s.nostore = 0; s.block_start = s.start; s.cfg = cfg;
@@ -264,8 +285,8 @@ void launch_lz_serial(const ChunkGeom &g, LevelCfg cfg, uint4 *tables, uint32_t 
     if (forced < 0) { const char *e = getenv("ZGPU_SERIAL_LANES"); forced = e ? atoi(e) : 0; if (forced < 0 || forced > 64) forced = 0; }
     uint32_t lanes = (uint32_t)forced;
     if (!lanes) { lanes = 1; while (lanes < 64 && (uint64_t)lanes * 4096 < g.nchunks) lanes <<= 1; }
-    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, 0u, tag);
-    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), 0, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, hand_on ? 1u : 0u, tag);
+    if (cfg.w_bits) hipLaunchKernelGGL(lz_serial_kernel<true>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), lanes * kSerialWinStride, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, 0u, tag);
+    else hipLaunchKernelGGL(lz_serial_kernel<false>, dim3((g.nchunks + lanes - 1) / lanes), dim3(64), lanes * kSerialWinStride, st, g, cfg, tables, tokens, meta, lanes, nostore_bits, hand_on ? 1u : 0u, tag);
 }
 
 } // namespace zgpu
