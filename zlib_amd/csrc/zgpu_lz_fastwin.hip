@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     uint32_t *tok = tokens + (size_t)cm * kChunkMax;
     const uint32_t base = chunk_base(g, c), npos = n >= 3 ? n - 2 : 0;
     uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
-    const uint32_t ring_a = fw_lds_base(fw_lds), stg_a = fw_lds_base(fw_lds + kFwOffStg) + lane * kFwStgStride;
+    const uint32_t ring_a = fw_lds_base(fw_lds);
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
 
     for (uint32_t i = lane; i < kFwFlagWords; i += 64) flags[i] = 0;
