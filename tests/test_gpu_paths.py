@@ -91,7 +91,7 @@ def test_chunks_the_loop_hands_on_come_out_the_same(monkeypatch):
             handed, offs2 = e.deflate_host(data, level, want_offsets=True)
             n_handed = e.L.zgpu_debug_handed_on(e.h) - before
             assert handed == plain and list(offs) == list(offs2)
-            assert 5 <= n_handed <= 7, n_handed  # the chunks that begin with random bytes
+            assert 5 <= n_handed <= 9, n_handed  # the chunks that begin with random bytes, and those that turn random later
             assert handed == O.deflate_stream(data.tobytes(), level)
             monkeypatch.delenv("ZGPU_HAND_ON")
     finally:

@@ -181,7 +181,7 @@ struct SerialLzT {
 // `hand_on` (deflate_fast only): this loop's time goes with the tokens of a chunk -- each one a chain of dependent memory accesses -- and a launch takes
 // as long as its slowest chunks: 4 GiB of the Silesia-mix take 377 ms at level 1, 232 ms without the 5 % of its chunks that do not compress (65 000
 // literals each), which the wave-per-chunk kernel does in 3.5 ms apiece (scripts/serial_classes.py).  So a lane that finds, every 4096 bytes, more than
-// seven tokens per ten bytes behind it gives the chunk up (returns false, the kernel marks it kHandedOn) and the engine runs zgpu_lz_fastwin.hip
+// one token per two bytes behind it (text has one per five) gives the chunk up (returns false, the kernel marks it kHandedOn) and the engine runs zgpu_lz_fastwin.hip
 // over the chunks given up.  Either kernel's tokens are the reference's, so who compresses a chunk shows in the time only.
 template <bool kSlow, bool kGeo>
 __device__ bool lz_serial_chunk(SerialLzT<kGeo> &s, bool hand_on)
@@ -194,7 +194,7 @@ __device__ bool lz_serial_chunk(SerialLzT<kGeo> &s, bool hand_on)
     uint32_t next_check = 4096;
     for (;;) {
         if (!kSlow && hand_on && p >= next_check) {
-            if ((uint64_t)s.ntok * 10 > (uint64_t)p * 7) return false;
+            if (s.ntok * 2 > p) return false;
             next_check += 4096;
         }
         if (buffered - p < kMinLookahead) { buffered = s.fill(p, buffered); if (n == p) break; }
