@@ -109,6 +109,7 @@ typedef struct {
     uint32_t block_start; /* chunk coords */
     bitsink bs;
     ora_token *tok_out; uint32_t tok_total; ora_chunk_info *info; uint32_t nblocks; int data_type;
+    int last_eob; /* last_eob_len, trees.c:1117 (compress_block), :1206 (copy_block: 8), :400 (_tr_init: 8) -- what _tr_align looks at */
 } enc;
 
 static void new_block(enc *e) /* init_block trees.c:411-424 */
@@ -276,17 +277,17 @@ static void close_block(enc *e, uint32_t p_end, int eof)
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
     } else opt_lenb = static_lenb = (uint64_t)stored_len + 5;
 
-    if ((uint64_t)stored_len + 4 <= opt_lenb && bs_w >= 0) { stored_block(e, e->in + e->block_start, stored_len, eof); btype = 0; }
+    if ((uint64_t)stored_len + 4 <= opt_lenb && bs_w >= 0) { stored_block(e, e->in + e->block_start, stored_len, eof); btype = 0; e->last_eob = 8; }
     else if (e->strategy == ORA_FIXED || static_lenb == opt_lenb) { /* trees.c:986 */
         put_bits(&e->bs, (1u << 1) + (unsigned)eof, 3);
-        emit_tokens(e, T_slcode, NULL, T_sllen, T_sdcode, NULL, 5); btype = 1;
+        emit_tokens(e, T_slcode, NULL, T_sllen, T_sdcode, NULL, 5); btype = 1; e->last_eob = 7;
     } else {
         put_bits(&e->bs, (2u << 1) + (unsigned)eof, 3);
         put_bits(&e->bs, (unsigned)(e->lt.max_code + 1 - 257), 5); put_bits(&e->bs, (unsigned)(e->dt.max_code + 1 - 1), 5);
         put_bits(&e->bs, (unsigned)(max_blindex + 1 - 4), 4);
         for (int r = 0; r <= max_blindex; r++) put_bits(&e->bs, e->bt.len[BLORDER[r]], 3);
         walk_lengths(e, &e->lt, e->lt.max_code, 1); walk_lengths(e, &e->dt, e->dt.max_code, 1);
-        emit_tokens(e, e->lt.code, e->lt.len, NULL, e->dt.code, e->dt.len, 0); btype = 2;
+        emit_tokens(e, e->lt.code, e->lt.len, NULL, e->dt.code, e->dt.len, 0); btype = 2; e->last_eob = e->lt.len[EOB];
     }
     if (e->info && e->nblocks < 8) e->info->btype[e->nblocks] = (uint32_t)btype;
     e->nblocks++;
@@ -506,4 +507,175 @@ size_t ora_deflate_stream_s(const uint8_t *in, size_t n, int level, int strategy
     uint32_t a = ora_adler32(1, in, n);
     out[o++] = (uint8_t)(a >> 24); out[o++] = (uint8_t)(a >> 16); out[o++] = (uint8_t)(a >> 8); out[o++] = (uint8_t)a;
     return o;
+}
+
+/* =====================================================================================================================
+ * The CONTINUOUS stream: one deflate stream over any number of bytes, driven call by call as an application drives
+ * deflate() (round 4).  Restates, on top of the per-chunk pieces above:
+ *   fill_window with every slide a long stream makes        qcsrc/deflate.c:1266-1358
+ *   deflate_stored / deflate_fast / deflate_slow as they RETURN need_more and are called again   :1390-1439, 1448-1546, 1554-1674
+ *   the flush arm of deflate(): _tr_align, the empty stored block, CLEAR_HASH                     :808-825, trees.c:892-915
+ *   deflateSetDictionary in front of the first byte          :315-354
+ * Coordinates: p is the offset into the whole input (uint32: streams below 4 GiB), the reference's window index is
+ * w = p - off where off grows by 32768 with every slide.  e->n is the end of what the window holds ("strstart + lookahead").
+ * What is NOT modelled: a caller that runs out of output space in the middle of a call (avail_out == 0) -- the blocks are the same,
+ * only the calls they leave in differ.
+ * ===================================================================================================================== */
+typedef struct {
+    uint32_t p;        /* strstart */
+    uint32_t filled;   /* strstart + lookahead: end of the bytes read into the window */
+    uint32_t avail;    /* end of the bytes the caller has handed over so far (next_in + avail_in) */
+    uint32_t match_len, match_start; int pending; /* deflate_slow's match_length, match_start, match_available (they live in the state, deflate.h:152-160) */
+} cstate;
+
+static void cont_fill(enc *e, cstate *c) /* fill_window */
+{
+    do {
+        refill(e, c->p);                                              /* the slide, when strstart has reached wsize + MAX_DIST */
+        const uint32_t more = 2 * WSIZE - (c->filled - c->p) - widx(e, c->p);
+        if (c->filled == c->avail) return;                            /* avail_in == 0 */
+        const uint32_t got = c->avail - c->filled < more ? c->avail - c->filled : more; /* read_buf */
+        c->filled += got;
+    } while (c->filled - c->p < MIN_LOOK && c->filled != c->avail);
+}
+
+/* returns 1 when the function ran to its flush (block_done / finish_done), 0 for need_more */
+static int cont_slow(enc *e, cstate *c, int flush)
+{
+    uint32_t prev_len, prev_match, hash_head = 0; /* (a local of deflate_slow: NIL again in every call, deflate.c:1558) */
+    int cut;
+    for (;;) {
+        if (c->filled - c->p < MIN_LOOK) {
+            cont_fill(e, c);
+            if (c->filled - c->p < MIN_LOOK && flush == 0) return 0;
+            if (c->filled == c->p) break;
+        }
+        const uint32_t look = c->filled - c->p, p = c->p;
+        e->n = c->filled;
+        if (look >= MINM) hash_head = insert_at(e, p);
+        prev_len = c->match_len; prev_match = c->match_start; c->match_len = MINM - 1;
+        if (hash_head != 0 && prev_len < e->cfg->lazy && widx(e, p) - hash_head <= (uint32_t)MAXDIST) {
+            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) c->match_len = best_match(e, p, hash_head, prev_len, &c->match_start);
+            else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) c->match_len = fast_match(e, p, hash_head, &c->match_start);
+            if (c->match_len <= 5 && (e->strategy == ORA_FILTERED || (c->match_len == MINM && p - c->match_start > FAR_LIMIT))) c->match_len = MINM - 1;
+        }
+        if (prev_len >= MINM && c->match_len <= prev_len) {
+            uint32_t max_insert = p + look - MINM, k = prev_len - 2, q = p;
+            cut = note_match(e, p - 1 - prev_match, prev_len - MINM);
+            do { if (++q <= max_insert) hash_head = insert_at(e, q); } while (--k != 0);
+            c->pending = 0; c->match_len = MINM - 1; c->p = q + 1;
+            if (cut) close_block(e, c->p, 0);
+        } else if (c->pending) {
+            cut = note_literal(e, e->in[p - 1]);
+            if (cut) close_block(e, p, 0);
+            c->p = p + 1;
+        } else { c->pending = 1; c->p = p + 1; }
+    }
+    if (c->pending) { note_literal(e, e->in[c->p - 1]); c->pending = 0; }
+    close_block(e, c->p, flush == 4);
+    return 1;
+}
+
+static int cont_fast(enc *e, cstate *c, int flush)
+{
+    uint32_t hash_head = 0;
+    int cut;
+    for (;;) {
+        if (c->filled - c->p < MIN_LOOK) {
+            cont_fill(e, c);
+            if (c->filled - c->p < MIN_LOOK && flush == 0) return 0;
+            if (c->filled == c->p) break;
+        }
+        uint32_t look = c->filled - c->p, p = c->p;
+        e->n = c->filled;
+        if (look >= MINM) hash_head = insert_at(e, p);
+        if (hash_head != 0 && widx(e, p) - hash_head <= (uint32_t)MAXDIST) {
+            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) c->match_len = best_match(e, p, hash_head, MINM - 1, &c->match_start);
+            else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) c->match_len = fast_match(e, p, hash_head, &c->match_start);
+        }
+        if (c->match_len >= MINM) {
+            cut = note_match(e, p - c->match_start, c->match_len - MINM);
+            look -= c->match_len;
+            if (c->match_len <= e->cfg->lazy && look >= MINM) {
+                c->match_len--;
+                do { p++; hash_head = insert_at(e, p); } while (--c->match_len != 0);
+                p++;
+            } else { p += c->match_len; c->match_len = 0; }
+        } else { cut = note_literal(e, e->in[p]); p++; }
+        c->p = p;
+        if (cut) close_block(e, p, 0);
+    }
+    close_block(e, c->p, flush == 4);
+    return 1;
+}
+
+static int cont_stored(enc *e, cstate *c, int flush)
+{
+    const uint32_t max_block = 65536 - 5 < 0xffff ? 65536 - 5 : 0xffff;
+    for (;;) {
+        if (c->filled - c->p <= 1) {
+            cont_fill(e, c);
+            if (c->filled == c->p && flush == 0) return 0;
+            if (c->filled == c->p) break;
+        }
+        uint32_t look;
+        c->p = c->filled; look = 0;
+        const uint32_t max_start = e->block_start + max_block;
+        if (c->p >= max_start) { look = c->p - max_start; c->p = max_start; close_block(e, c->p, 0); }
+        (void)look; /* (the bytes behind max_start stay in the window as lookahead: filled does not move) */
+        if (c->p - e->block_start >= (uint32_t)MAXDIST) close_block(e, c->p, 0);
+    }
+    close_block(e, c->p, flush == 4);
+    return 1;
+}
+
+static void cont_align(enc *e) /* _tr_align, trees.c:892-915; the bit sink holds fewer than 8 bits between calls, which is bi_valid after bi_flush */
+{
+    put_bits(&e->bs, 1u << 1, 3); put_bits(&e->bs, T_slcode[EOB], T_sllen[EOB]);
+    if (1 + e->last_eob + 10 - e->bs.nacc < 9) { put_bits(&e->bs, 1u << 1, 3); put_bits(&e->bs, T_slcode[EOB], T_sllen[EOB]); }
+    e->last_eob = 7;
+}
+
+/* in[0 .. dict_len) is the part of a preset dictionary the window receives (the caller cuts it to its last MAX_DIST bytes; 0: none), the data
+ * follow; n counts both.  Call k hands deflate() the bytes up to offset cuts[k] (offsets into the DATA, ascending) with flush kinds[k]
+ * (0 Z_NO_FLUSH, 1 Z_PARTIAL_FLUSH, 2 Z_SYNC_FLUSH, 3 Z_FULL_FLUSH); one more call hands over the rest with Z_FINISH.
+ * Output: the raw deflate stream.  Returns its length, 0 when cap is too small or an argument is off. */
+size_t ora_deflate_cont(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds, size_t ncuts,
+                        uint8_t *out, size_t cap)
+{
+    if (n >= 0xfff00000u || dict_len > n || (dict_len != 0 && (dict_len < MINM || dict_len > MAXDIST))) return 0;
+    if (level < 0 || level > 9 || strategy < 0 || strategy > ORA_FIXED) return 0;
+    make_tables();
+    enc *e = (enc *)calloc(1, sizeof(enc));
+    if (!e) return 0;
+    e->in = in; e->n = (uint32_t)dict_len; e->level = level; e->strategy = strategy; e->cfg = &LEVELS[level];
+    e->bs.out = out; e->bs.cap = cap; e->data_type = 2; e->last_eob = 8;
+    new_block(e);
+    e->start = (uint32_t)dict_len; e->block_start = e->start;
+    for (uint32_t q = 0; q + MINM <= e->start; q++) insert_at(e, q);
+    cstate c; memset(&c, 0, sizeof c);
+    c.p = c.filled = c.avail = (uint32_t)dict_len; c.match_len = MINM - 1;
+    int prev_flush = 0;
+    for (size_t k = 0; k <= ncuts; k++) {
+        const int flush = k == ncuts ? 4 : kinds[k];
+        const uint32_t upto = k == ncuts ? (uint32_t)n : (uint32_t)dict_len + cuts[k];
+        if (upto < c.avail || upto > n || flush < 0 || flush > 4 || (k < ncuts && flush == 4)) { free(e); return 0; }
+        if (upto == c.avail && flush <= prev_flush && flush != 4) { free(e); return 0; } /* the reference answers Z_BUF_ERROR, deflate.c:774-777 */
+        const int had_in = upto != c.avail;
+        c.avail = upto; prev_flush = flush;
+        if (!(had_in || c.filled != c.p || flush != 0)) continue; /* deflate.c:786-787 */
+        const int done = e->cfg->mode == 2 ? cont_slow(e, &c, flush) : e->cfg->mode == 1 ? cont_fast(e, &c, flush) : cont_stored(e, &c, flush);
+        if (done && flush != 4) { /* block_done, deflate.c:808-819 */
+            if (flush == 1) cont_align(e);
+            else {
+                put_bits(&e->bs, 0, 3); byte_align(&e->bs);
+                sink_byte(&e->bs, 0); sink_byte(&e->bs, 0); sink_byte(&e->bs, 0xff); sink_byte(&e->bs, 0xff);
+                e->last_eob = 8;
+                if (flush == 3) memset(e->head, 0, sizeof e->head); /* CLEAR_HASH */
+            }
+        }
+    }
+    const size_t len = e->bs.overflow ? 0 : e->bs.len;
+    free(e);
+    return len;
 }

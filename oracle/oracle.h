@@ -69,6 +69,12 @@ size_t ora_deflate_stream(const uint8_t *in, size_t n, int level, size_t chunk_s
 /* worst-case output of ora_deflate_stream (compress.c:75-79 bound per chunk, plus framing). */
 size_t ora_deflate_bound(size_t n, size_t chunk_size);
 
+/* The CONTINUOUS stream (deflate_oracle.c, last section): one raw deflate stream over dict + data, driven call by call -- call k hands over the data
+ * up to offset cuts[k] with flush kinds[k] (0 none, 1 partial, 2 sync, 3 full), a last call the rest with Z_FINISH.  in[0..dict_len) = what
+ * deflateSetDictionary puts into the window (<= 32506 bytes); n counts both.  What plain compress2() emits is ncuts == 0. */
+size_t ora_deflate_cont(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds, size_t ncuts,
+                        uint8_t *out, size_t cap);
+
 /* adler32.c:57-125 and :128-149 */
 uint32_t ora_adler32(uint32_t adler, const uint8_t *buf, size_t len);
 uint32_t ora_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);

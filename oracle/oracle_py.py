@@ -41,6 +41,8 @@ def lib():
         L.ora_deflate_stream_s.restype = C.c_size_t
         L.ora_deflate_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ora_deflate_stream.restype = C.c_size_t
+        L.ora_deflate_cont.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ora_deflate_cont.restype = C.c_size_t
         L.ora_deflate_bound.argtypes = [C.c_size_t, C.c_size_t]
         L.ora_deflate_bound.restype = C.c_size_t
         L.ora_adler32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
@@ -146,3 +148,18 @@ def inflate_raw(data: bytes, outcap: int):
 
 def inflate_zlib(data: bytes, outcap: int):
     return _inflate(lib().ora_inflate_zlib, data, outcap)
+
+
+def deflate_cont(data: bytes, level: int, calls=(), strategy: int = 0, dictionary: bytes = b"") -> bytes:
+    """The continuous raw stream (ora_deflate_cont): calls = [(upto, flush), ...] as in refzlib.deflate_calls; the Z_FINISH call is implied."""
+    L = lib()
+    d = dictionary[-32506:] if dictionary and len(dictionary) >= 3 else b""
+    buf = d + data
+    cuts = (C.c_uint32 * max(len(calls), 1))(*[u for u, _ in calls])
+    kinds = (C.c_int32 * max(len(calls), 1))(*[f for _, f in calls])
+    cap = len(data) + (len(data) >> 3) + 64 * (len(calls) + 2) + 1024
+    out = C.create_string_buffer(cap)
+    n = L.ora_deflate_cont(buf, len(buf), len(d), level, strategy, cuts, kinds, len(calls), out, cap)
+    if n == 0:
+        raise RuntimeError("oracle deflate_cont failed")
+    return out.raw[:n]

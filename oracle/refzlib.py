@@ -277,3 +277,32 @@ def inflate_raw(data: bytes, outcap: int):
 def inflate_zlib(data: bytes, outcap: int):
     rc, out = uncompress(data, outcap)
     return rc, out
+
+
+def deflate_calls(data: bytes, level: int, calls=(), wbits: int = -15, strategy: int = 0, dictionary: bytes = None) -> bytes:
+    """ONE stream of the reference driven call by call: for (upto, flush) in calls, deflate() is handed data[fed:upto] with that flush
+    value (Z_NO_FLUSH slices the input, Z_SYNC_FLUSH / Z_FULL_FLUSH / Z_PARTIAL_FLUSH flush); a last call hands over the rest with
+    Z_FINISH.  calls == () is what compress2() does (qcsrc/compress.c:22-58).  Output space is never short."""
+    L = lib()
+    s = ZStream()
+    rc = L.deflateInit2_(C.byref(s), level, Z_DEFLATED, wbits, 8, strategy, b"1.2.3", C.sizeof(ZStream))
+    assert rc == Z_OK, rc
+    if dictionary is not None:
+        rc = L.deflateSetDictionary(C.byref(s), dictionary, len(dictionary))
+        assert rc == Z_OK, rc
+    cap = len(data) + (len(data) >> 3) + 64 * (len(calls) + 2) + 1024
+    out = C.create_string_buffer(cap)
+    inb = C.create_string_buffer(data, max(len(data), 1))
+    s.next_out = C.addressof(out); s.avail_out = cap
+    fed = 0
+    for upto, flush in list(calls) + [(len(data), Z_FINISH)]:
+        s.next_in = C.addressof(inb) + fed; s.avail_in = upto - fed
+        rc = L.deflate(C.byref(s), flush)
+        want = Z_STREAM_END if flush == Z_FINISH else Z_OK
+        if rc != want or s.avail_in != 0:
+            L.deflateEnd(C.byref(s))
+            raise RuntimeError("reference deflate rc=%d avail_in=%d (flush %d at %d)" % (rc, s.avail_in, flush, upto))
+        fed = upto
+    n = s.total_out
+    L.deflateEnd(C.byref(s))
+    return out.raw[:n]
