@@ -47,6 +47,11 @@ extern "C" {
                                the body, CRC-32 and length little-endian (deflate.c:833-843); needs FINAL */
 #define ZGPU_F_CRC32 32u     /* also compute the CRC-32 of the input (result.crc32) without writing a wrapper */
 
+#define ZGPU_F_CONTINUOUS 64u /* zgpu_deflate_device / zgpu_deflate_host: the input as ONE continuous stream, byte for byte what the reference's un-flushed
+                                deflate() -- plain compress2(), qcsrc/compress.c:22-58 -- emits: the 32 KiB window slides through the whole input
+                                (qcsrc/deflate.c:1266-1358), matches cross every 64 KiB boundary, blocks are cut every 16383 tokens counted from the
+                                stream's start (h/deflate.h:313).  Needs FINAL; chunk_size, POS0*, prime do not apply; no chunk table. */
+
 /* LZ77 match-finder implementation selector (debug / A-B measurements) */
 #define ZGPU_LZ_AUTO 0
 #define ZGPU_LZ_SERIAL 1   /* one lane per chunk, tables in HBM: any level 1..9 */
@@ -149,6 +154,38 @@ int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, con
  * receives nchunks+1 offsets. */
 int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const zgpu_deflate_params *p, void *out,
                       uint64_t out_cap, uint64_t *chunk_offsets, zgpu_deflate_result *res);
+
+/* ---- ONE continuous stream, feed by feed (zlib_amd/csrc/zgpu_cont.hip): what deflate() of the zlib API is built on ----
+ * The stream's state between feeds lives with the CALLER (zgpu_cont_state + the tokens of the block that is still filling); the engine keeps nothing.
+ * All positions are positions in the stream (a preset dictionary's bytes count: the first one is position 0).
+ *   buf        the bytes the parse can still reach followed by the bytes it has not parsed: buf[0] is stream position cs->abs0, which must be at most
+ *              cs->entry - 32512 (or 0) -- and at most cs->block_start when that lies within 65536 + 512 of cs->entry (a block that may still be stored
+ *              is copied from there)
+ *   check_from offset into buf of the first byte this feed brings: res->adler32 / crc32 cover buf[check_from ..) alone (buf_bytes: nothing)
+ *   mode       ZGPU_CONT_MORE: more input follows; the parse stops 512 bytes (or a little less) in front of the end of buf and cs->entry says where --
+ *              the caller keeps the bytes from cs->entry - 32512 on for the next feed.  ZGPU_CONT_FLUSH: the segment ends here as at Z_SYNC_FLUSH /
+ *              Z_PARTIAL_FLUSH / Z_FULL_FLUSH (lookahead runs out at the end of buf, the block that is filling is closed; the marker behind it is the
+ *              caller's to write -- it knows cs->bit_count / bit_value and cs->last_eob).  ZGPU_CONT_FINISH: the same with the final bit, padded to a byte.
+ *   excl       stream positions inside buf's history that are NOT in the hash chains: the two in front of every earlier flush point (zlib 1.2.3 never
+ *              inserts them, qcsrc/deflate.c:1576 with lookahead < MIN_MATCH)
+ *   out        whole bytes of the stream from the byte the last feed left unfinished (cs->bit_count bits of it are in cs->bit_value); res->out_bytes */
+#define ZGPU_CONT_MORE 0
+#define ZGPU_CONT_FLUSH 1
+#define ZGPU_CONT_FINISH 2
+#define ZGPU_CONT_CARRY_TOKENS 16384
+typedef struct {
+    uint64_t abs0;        /* in: stream position of buf[0] */
+    uint64_t entry;       /* in/out: stream position the parse stands at with nothing in hand (deflate_slow between two matches) */
+    uint64_t block_start; /* in/out: stream position of the first byte of the block that is filling */
+    uint32_t carry_ntok;  /* in/out: tokens of that block so far (in carry_tok) */
+    uint32_t bit_count, bit_value; /* in/out: bits of the stream's next byte that are decided already (0..7 of them) */
+    uint32_t data_type;   /* in/out: 2 (Z_UNKNOWN) until the first block has decided */
+    uint32_t first_block; /* in/out: 1 until the stream's first block is out */
+    uint32_t last_eob;    /* in/out: last_eob_len (qcsrc/trees.c:1117) -- what _tr_align looks at; 8 for a fresh stream */
+} zgpu_cont_state;
+uint64_t zgpu_deflate_cont_bound(uint64_t buf_bytes); /* output capacity that is enough for one feed */
+int zgpu_deflate_cont_host(zgpu_engine *e, const void *buf, uint64_t buf_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode, zgpu_cont_state *cs,
+                           uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res);
 
 /* Batch of independent small buffers: segment k = in[seg_offsets[k] .. seg_offsets[k+1]), each at most
  * 65536 bytes, becomes one chunk.  With ZGPU_F_FINAL every segment is a complete raw-deflate stream of its

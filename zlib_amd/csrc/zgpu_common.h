@@ -72,11 +72,19 @@ struct ChunkGeom {
     // A launch over a LIST of the batch's chunks (levels 1-3: the chunks the lane-per-chunk loop handed on, zgpu_engine.hip): workgroup c works on
     // chunk chunk_map[c] of the batch -- the input, tokens and meta of that chunk; its scratch (sorted buckets) is slot c.  nullptr: chunk c.
     const uint32_t *chunk_map;
+    // Continuous stream (round 4, zgpu_cont.hip): tile_stride != 0 makes "chunk" c of the launch the TILE chunk0 + c -- the 64 KiB of the buffer that start at
+    // tile_w0 + (chunk0 + c) * tile_stride, clipped at in_bytes.  Tiles overlap: each brings the 32512 bytes in front of its own positions along as history.
+    uint64_t tile_w0;
+    uint32_t tile_stride;
+    // positions of the buffer (ascending buffer offsets) that are NOT in the hash chains although they have three bytes: the two positions in front of every
+    // earlier Z_SYNC_FLUSH / Z_PARTIAL_FLUSH point (lookahead < MIN_MATCH when the loop stood there, deflate.c:1470,1576; zlib 1.2.3 never inserts them later)
+    const uint64_t *excl; uint32_t nexcl;
 };
 __device__ inline uint32_t chunk_of(const ChunkGeom &g, uint32_t c) { return g.chunk_map ? g.chunk_map[c] : c; }
 __device__ inline void chunk_span(const ChunkGeom &g, uint32_t c, uint64_t &lo, uint32_t &n)
 {
     const uint64_t gc = g.chunk0 + chunk_of(g, c);
+    if (g.tile_stride) { lo = g.tile_w0 + gc * g.tile_stride; const uint64_t rem = g.in_bytes - lo; n = (uint32_t)(rem < kChunkMax ? rem : kChunkMax); return; }
     if (g.seg_off) { lo = g.seg_off[gc]; n = (uint32_t)(g.seg_off[gc + 1] - lo); }
     else { lo = gc * g.chunk_size; uint64_t rem = g.in_bytes - lo; n = (uint32_t)(rem < g.chunk_size ? rem : g.chunk_size); }
 }
@@ -84,6 +92,64 @@ __device__ inline bool chunk_is_final(const ChunkGeom &g, uint32_t c) { return g
 __device__ inline uint32_t chunk_skip(const ChunkGeom &g, uint32_t c) { return g.chunk0 + chunk_of(g, c) == 0 ? g.skip0 : 0u; }
 __device__ inline uint32_t chunk_prime(const ChunkGeom &g, uint32_t c) { return g.chunk0 + chunk_of(g, c) == 0 ? g.prime : 0u; }
 __device__ inline uint32_t chunk_base(const ChunkGeom &g, uint32_t c) { return (g.pos0_mode == 2 || (g.pos0_mode == 1 && g.chunk0 + chunk_of(g, c) != 0)) ? 3u : 0u; }
+
+// ---- continuous stream: tiles (see zgpu_cont.hip) ----
+constexpr uint32_t kTileStride = 32512;            // positions a tile parses = bytes of history it brings along (MAX_DIST = 32506 fits)
+constexpr uint32_t kTileH1 = 2 * kTileStride;      // a tile parses the local positions [h0, h1) = [32512, 65024) (the first tile of a feed: from its entry)
+constexpr uint32_t kTileSlack = kChunkMax - kTileH1; // 512: a game that starts below h1 searches up to 254 positions further (each lazy step needs a longer match) and needs MAX_MATCH of lookahead there
+constexpr uint32_t kTileEntries = kTileSlack + 1;  // where a tile can be entered: h0 + 0 .. 512 (the last game of the tile before ends at most 512 behind its h1)
+constexpr uint32_t kTileExitStride = 520;          // u16 per tile: exit (relative to h1) as a function of the entry (relative to h0)
+struct TileGeom {
+    uint64_t abs0;     // stream position of the buffer's first byte
+    uint64_t e0;       // buffer offset of the neutral position the first tile of the feed is entered at (>= tile_w0, at most kTileStride above it)
+    uint64_t end;      // buffer offset the parse runs up to: in_bytes when the segment ends there (flush / finish), else in_bytes - kTileSlack
+    uint64_t nil_pos;  // buffer offset of the one position whose first candidate, exactly MAX_DIST back, is NIL (slid out at that very loop top), ~0: none
+    uint32_t abs0_nil; // stream position 0 is NIL (a stream without dictionary: window index 0 is never a candidate, deflate.c:1479)
+    uint32_t pad;
+    uint16_t *exits;   // [tile of the launch][kTileExitStride]
+    uint16_t *entry;   // [tile of the feed]: where the parse enters the tile, relative to its h0
+};
+__device__ inline void tile_span(const ChunkGeom &g, const TileGeom &tg, uint32_t c, uint64_t &wb, uint32_t &nloc, uint32_t &h0, uint32_t &h1, uint32_t &nent)
+{
+    const uint64_t ti = g.chunk0 + c;
+    wb = g.tile_w0 + ti * g.tile_stride;
+    const uint64_t rem = g.in_bytes - wb, lim = tg.end > wb ? tg.end - wb : 0;
+    nloc = (uint32_t)(rem < kChunkMax ? rem : kChunkMax);
+    h0 = ti == 0 ? (uint32_t)(tg.e0 - g.tile_w0) : kTileStride;
+    h1 = (uint32_t)(lim < kTileH1 ? lim : kTileH1);
+    if (h1 < h0) h1 = h0;
+    nent = ti == 0 ? 1u : kTileEntries;
+}
+
+// One block of a continuous stream (blocks are cut every 16383 tokens counted from the start of the STREAM, h/deflate.h:313): filled in by cont_table_kernel,
+// coded by huffman_kernel<true> into a slot of its own from bit 0, put in its place in the stream (a bit position) by cont_stitch_kernel.
+struct ContBlk {
+    uint64_t end_pos;    // buffer offset behind the block's last byte
+    uint64_t start_pos;  // buffer offset of its first byte (stored blocks are copied from there)
+    uint32_t last_len;   // bytes its last token covers: the loop stood at end_pos - last_len + 1 when the block was flushed
+    uint32_t tok0, nt;   // its tokens in the batch's compact token array
+    uint32_t eof;        // the stream's final block
+    uint32_t nostore;    // its first byte has left the reference's window by the time it is flushed (buf == NULL, deflate.c:1364-1367)
+    uint32_t first;      // the stream's first block: decides strm->data_type (trees.c:934-935)
+    uint32_t nbits;      // out: bits of the coded block (btype 1, 2)
+    uint32_t btype;      // out: 0 stored, 1 static, 2 dynamic
+    uint32_t stored_len; // out: bytes of input the block covers
+    uint32_t eob_len;    // out: last_eob_len behind it (trees.c:1117,1206)
+};
+// carried from batch to batch on the device and from feed to feed through the host
+struct ContState {
+    uint64_t out_bits;    // bit position in the output where the next block starts
+    uint64_t block_start; // buffer offset of the first byte of the block that is being filled
+    uint64_t ntokens;     // (diagnostic)
+    uint64_t e_next;      // buffer offset of the neutral position the parse has reached
+    uint32_t carry_n;     // tokens of the block being filled that are waiting in the carry buffer
+    uint32_t data_type;   // Z_UNKNOWN 2 until the first block has decided
+    uint32_t last_eob;
+    uint32_t overflow;
+    uint32_t nblk, total; // the current batch: blocks to emit, tokens in the compact array (carry included)
+    uint32_t first_block; // 1 until the stream's first block has been emitted
+    uint32_t entry_k;     // entry of the next batch's first tile relative to its h0 (the chain's hand-over)
+};
 
 // token: bits 0..7 = literal byte or (match length - 3); bits 8..23 = match distance (0 for a literal)
 __host__ __device__ inline uint32_t tok_lit(uint32_t c) { return c; }

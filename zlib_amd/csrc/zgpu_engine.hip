@@ -30,6 +30,16 @@ size_t lz_sorted_workspace_bytes(uint32_t batch_chunks);
 bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, int walk);
 bool lz_fastwin_serves(const LevelCfg &cfg);
 uint32_t *lz_sorted_fault_word(void *workspace);
+// continuous stream (zgpu_cont.hip, zgpu_lz_sorted.hip)
+void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, uint16_t *comp, uint16_t *gentry, hipStream_t st,
+                     void *prof, int exact_sort);
+uint32_t chain_groups(uint32_t ntiles);
+void launch_cont_tokens(const ChunkGeom &g, const TileGeom &tg, const uint32_t *tokens, const ChunkMeta *tmeta, ContState *st, uint32_t *tokoff, const uint32_t *carry, uint32_t *T,
+                        ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, hipStream_t s);
+void launch_huffman_cont(const ChunkGeom &g, const uint32_t *compact_tokens, uint32_t nblk, ContBlk *blk, ContState *cst, uint8_t *slots, hipStream_t st, bool fixed_trees);
+void launch_cont_stitch(const ContBlk *blk, ContState *st, uint64_t *pos, const uint8_t *slots, uint32_t slot_stride, const uint8_t *in, uint64_t abs0, uint8_t *out, uint64_t out_cap,
+                        uint32_t nblk_cap, const uint32_t *T, uint32_t *carry, uint64_t seg_end, hipStream_t s);
+uint64_t cont_special_pos(uint64_t n);
 int inflate_run(struct ::zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const uint64_t *d_offsets, uint64_t nchunks,
                 uint32_t chunk_size, uint8_t *d_out, uint64_t out_cap, zgpu_inflate_result *res, hipStream_t st, uint32_t stream_mode = 0,
                 const uint64_t *h_offsets = nullptr, bool open_end = false, uint8_t *h_dst = nullptr, uint64_t h_cap = 0);
@@ -76,6 +86,13 @@ struct zgpu_engine {
     void *inf_slots = nullptr; uint64_t inf_slots_cap = 0;
     uint8_t *inf_dict = nullptr; uint32_t inf_dict_len = 0; // preset dictionary of the next inflate calls (zgpu_inflate_set_dictionary)
     uint32_t inf_checks = 3;                                // checks of the decoded bytes (zgpu_inflate_set_checks)
+    // continuous stream (deflate_cont): per batch of tiles / per feed
+    uint32_t ct_tiles = 0, ct_nblk = 0; uint64_t ct_feed_tiles = 0;
+    uint16_t *ct_exits = nullptr, *ct_entry = nullptr, *ct_comp = nullptr, *ct_gentry = nullptr;
+    uint32_t *ct_tokoff = nullptr, *ct_T = nullptr, *ct_carry = nullptr, *ct_carry_in = nullptr;
+    zgpu::ContBlk *ct_blk = nullptr; uint64_t *ct_pos = nullptr; uint8_t *ct_slots = nullptr; zgpu::ContState *ct_st = nullptr;
+    zgpu::ChunkMeta *ct_ckmeta = nullptr; uint64_t ct_ck_cap = 0;
+    uint64_t *ct_excl = nullptr; uint32_t ct_excl_cap = 0;
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -469,6 +486,179 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
 ChunkMeta *engine_meta(zgpu_engine *e, uint32_t batch);
 uint64_t *engine_offsets_scratch(zgpu_engine *e, uint64_t n);
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// One FEED of a continuous stream (zgpu_cont.hip has the plan): d_buf holds the history the parse can still reach followed by the bytes that have
+// not been parsed yet, cs says where the stream stands (absolute stream positions) and receives where it stands afterwards, d_carry_in holds the
+// tokens of the block that is filling (device memory, cs->carry_ntok words, not e->ct_carry); the ones the feed leaves behind are in e->ct_carry.  The output starts at bit cs->bit_count of d_out's byte 0 ... in general at bit
+// `prefix_bits` of d_out: the caller has put the bytes in front (a wrapper's header) and the bits of the unfinished byte there, zero-filled to a whole word.
+constexpr uint32_t kContCarry = 16384;
+static int ensure_cont_ws(zgpu_engine *e, uint32_t batch_tiles, uint64_t feed_tiles)
+{
+    int rc;
+    if (!e->ct_st) {
+        if ((rc = dev_alloc(e, &e->ct_st, 1))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_carry, kContCarry))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_carry_in, kContCarry))) return rc;
+    }
+    if (feed_tiles + 2 > e->ct_feed_tiles) {
+        hipFree(e->ct_entry); e->ct_entry = nullptr; e->ct_feed_tiles = 0;
+        if ((rc = dev_alloc(e, &e->ct_entry, feed_tiles + 2 + 1024))) return rc;
+        e->ct_feed_tiles = feed_tiles + 2 + 1024;
+    }
+    if (batch_tiles > e->ct_tiles) {
+        hipFree(e->ct_exits); hipFree(e->ct_comp); hipFree(e->ct_gentry); hipFree(e->ct_tokoff); hipFree(e->ct_T); hipFree(e->ct_blk); hipFree(e->ct_pos); hipFree(e->ct_slots);
+        e->ct_exits = e->ct_comp = e->ct_gentry = nullptr; e->ct_tokoff = e->ct_T = nullptr; e->ct_blk = nullptr; e->ct_pos = nullptr; e->ct_slots = nullptr; e->ct_tiles = 0;
+        const size_t ntok_cap = (size_t)kContCarry + kChunkMax + (size_t)batch_tiles * (kTileStride + kTileSlack); // tile 0 of a feed parses up to 65024 positions, the others 32512, + the last game's overhang
+        const uint32_t nblk_cap = (uint32_t)(ntok_cap / kBlockTokens + 2);
+        const uint32_t ngroups = chain_groups(batch_tiles);
+        if ((rc = dev_alloc(e, &e->ct_exits, (size_t)batch_tiles * kTileExitStride))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_comp, (size_t)ngroups * kTileExitStride))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_gentry, (size_t)ngroups + 1))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_tokoff, (size_t)batch_tiles + 1))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_T, ntok_cap))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_blk, (size_t)nblk_cap))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_pos, (size_t)nblk_cap + 1))) return rc;
+        if ((rc = dev_alloc(e, &e->ct_slots, (size_t)nblk_cap * kSlotStride))) return rc;
+        e->ct_tiles = batch_tiles; e->ct_nblk = nblk_cap;
+    }
+    return ZGPU_OK;
+}
+
+struct ContFeed { // one call of deflate_cont
+    const uint8_t *d_buf; uint64_t buf_bytes; // history + unparsed bytes
+    uint64_t check_from;                      // Adler-32 / CRC-32 of d_buf[check_from ..): the bytes this feed brought (buf_bytes: none)
+    int mode;                                 // ZGPU_CONT_*
+    const uint64_t *h_excl; uint32_t nexcl;   // stream positions that are not in the hash chains (in front of earlier flushes), ascending
+    uint8_t *d_out; uint64_t out_cap; uint64_t prefix_bits;
+    bool want_crc;
+};
+static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, zgpu_cont_state *cs, const uint32_t *d_carry_in, zgpu_deflate_result *res, hipStream_t st)
+{
+    if (!cfg.slow) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: levels 4..9");
+    if (cs->entry < cs->abs0 || cs->entry > cs->abs0 + f.buf_bytes || cs->carry_ntok >= kBlockTokens || cs->bit_count > 7) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: state out of range");
+    if ((reinterpret_cast<uintptr_t>(f.d_out) & 3) != 0) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: the output must be 4-byte aligned");
+    const uint64_t e0 = cs->entry - cs->abs0, w0 = e0 > kTileStride ? e0 - kTileStride : 0;
+    const bool ends = f.mode != ZGPU_CONT_MORE;
+    const uint64_t end = ends ? f.buf_bytes : (f.buf_bytes > kTileSlack ? f.buf_bytes - kTileSlack : 0);
+    const uint64_t ntiles = end > e0 ? (end <= w0 + kTileH1 ? 1 : (end - w0 - kTileH1 + kTileStride - 1) / kTileStride + 1) : 0;
+    if (!ends && ntiles == 0) { res->out_bytes = 0; res->nchunks = 0; res->ntokens = 0; res->adler32 = 1; res->crc32 = 0; res->data_type = cs->data_type; if (f.check_from < f.buf_bytes) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: a feed that parses nothing brings no bytes"); return ZGPU_OK; }
+    uint32_t batch_max = env_u32("ZGPU_CONT_BATCH_TILES", 32768);
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t per_tile = lz_sorted_workspace_bytes(1) + (size_t)kChunkMax * 4 + (size_t)(kTileStride + kTileSlack) * 4 + 3 * (size_t)kSlotStride + kSlotStride;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t held = (size_t)e->ct_tiles * per_tile;
+            size_t fit = (free_b + held) / 10 * 6 / per_tile;
+            if (fit < 64) fit = 64;
+            if (fit < batch_max) batch_max = (uint32_t)fit;
+        }
+    }
+    const uint32_t batch = (uint32_t)(ntiles < batch_max ? (ntiles ? ntiles : 1) : batch_max);
+    int rc = ensure_deflate_ws(e, batch, false, 1);
+    if (rc) return rc;
+    if ((rc = ensure_cont_ws(e, batch, ntiles))) return rc;
+    const uint64_t seg_end = ends ? cs->abs0 + f.buf_bytes : ~0ull, sp = ends ? cont_special_pos(seg_end) : ~0ull;
+    uint32_t nexcl_dev = 0;
+    if (f.nexcl) {
+        if (f.nexcl > e->ct_excl_cap) { hipFree(e->ct_excl); e->ct_excl = nullptr; e->ct_excl_cap = 0; if ((rc = dev_alloc(e, &e->ct_excl, (size_t)f.nexcl + 64))) return rc; e->ct_excl_cap = f.nexcl + 64; }
+        std::vector<uint64_t> off(f.nexcl);
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < f.nexcl; i++) if (f.h_excl[i] >= cs->abs0 && f.h_excl[i] - cs->abs0 < f.buf_bytes) off[k++] = f.h_excl[i] - cs->abs0; // (buffer offsets)
+        ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_excl, off.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        nexcl_dev = k;
+    }
+    ContState hs{};
+    hs.out_bits = f.prefix_bits; hs.block_start = cs->block_start; hs.carry_n = cs->carry_ntok; hs.data_type = cs->data_type; hs.last_eob = cs->last_eob;
+    hs.first_block = cs->first_block; hs.e_next = cs->entry;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_st, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    { const uint16_t z = 0; ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_entry, &z, 2, hipMemcpyHostToDevice, st)); }
+    const bool check_sort = !e->exact_sort;
+    uint32_t sort_fault = 0;
+    if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
+
+    ChunkGeom g{};
+    g.in = f.d_buf; g.in_bytes = f.buf_bytes; g.chunk_size = kChunkMax; g.final_chunk = ~0ull; g.block_tokens = kBlockTokens; g.slot_stride = kSlotStride;
+    g.tile_w0 = w0; g.tile_stride = kTileStride; g.excl = nexcl_dev ? e->ct_excl : nullptr; g.nexcl = nexcl_dev;
+    TileGeom tg{};
+    tg.abs0 = cs->abs0; tg.e0 = e0; tg.end = end; tg.nil_pos = (sp != ~0ull && sp >= cs->abs0 && sp < seg_end) ? sp - cs->abs0 : ~0ull; tg.abs0_nil = 1;
+    tg.exits = e->ct_exits; tg.entry = e->ct_entry;
+    const uint64_t out_cap4 = f.out_cap & ~3ull;
+    for (uint64_t t0 = 0; t0 == 0 || t0 < ntiles; t0 += batch) { // (a feed without tiles still closes the block that is filling)
+        const uint32_t nb = (uint32_t)(ntiles - t0 < batch ? ntiles - t0 : batch);
+        const bool last_batch = t0 + nb >= ntiles;
+        g.chunk0 = t0; g.nchunks = nb;
+        if (nb) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
+        const uint64_t seg_here = (ends && last_batch) ? seg_end : ~0ull;
+        {
+            StageTimer t(e, st, ZGPU_STAGE_PARSE);
+            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, st);
+        }
+        {
+            StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
+            launch_huffman_cont(g, e->ct_T, e->ct_nblk, e->ct_blk, e->ct_st, e->ct_slots, st, cfg.strategy == kFixed);
+        }
+        {
+            StageTimer t(e, st, ZGPU_STAGE_STITCH);
+            launch_cont_stitch(e->ct_blk, e->ct_st, e->ct_pos, e->ct_slots, kSlotStride, f.d_buf, cs->abs0, f.d_out, out_cap4, e->ct_nblk, e->ct_T, e->ct_carry, seg_here, st);
+        }
+        const hipError_t he = hipGetLastError();
+        if (he != hipSuccess) return zgpu::fail_hip(e, he, "kernel launch", __FILE__, __LINE__);
+        if (ntiles == 0) break;
+    }
+    // checksums of the bytes this feed brought
+    uint32_t adler = 1, crc = 0;
+    if (f.check_from < f.buf_bytes) {
+        const uint64_t nbytes = f.buf_bytes - f.check_from, nck = (nbytes + kChunkMax - 1) / kChunkMax;
+        const uint32_t cb = (uint32_t)(nck < 65536 ? nck : 65536);
+        if (cb > e->ct_ck_cap) { hipFree(e->ct_ckmeta); e->ct_ckmeta = nullptr; e->ct_ck_cap = 0; if ((rc = dev_alloc(e, &e->ct_ckmeta, (size_t)cb))) return rc; e->ct_ck_cap = cb; }
+        uint64_t *offs = engine_offsets_scratch(e, nck + 1);
+        if (!offs) return fail(e, ZGPU_MEM_ERROR, "checksum scratch");
+        StageTimer t(e, st, ZGPU_STAGE_STITCH);
+        RunStateHost rs{}; rs.adler_a = 1;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(e->run, &rs, sizeof rs, hipMemcpyHostToDevice, st));
+        for (uint64_t c0 = 0; c0 < nck; c0 += cb) {
+            const uint32_t nbk = (uint32_t)(nck - c0 < cb ? nck - c0 : cb);
+            ZGPU_HIP_CHECK(hipMemsetAsync(e->ct_ckmeta, 0, (size_t)nbk * sizeof(ChunkMeta), st));
+            ChunkGeom g2{}; g2.in = f.d_buf + f.check_from; g2.in_bytes = nbytes; g2.chunk_size = kChunkMax; g2.chunk0 = c0; g2.nchunks = nbk; g2.final_chunk = ~0ull;
+            launch_adler(g2, e->ct_ckmeta, st);
+            if (f.want_crc) launch_crc(g2, e->ct_ckmeta, st);
+            launch_scan(e->ct_ckmeta, nbk, c0, offs, e->run, ~0ull, st, f.want_crc);
+        }
+        ZGPU_HIP_CHECK(hipMemcpyAsync(&rs, e->run, sizeof rs, hipMemcpyDeviceToHost, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        adler = rs.adler_a | (rs.adler_b << 16); crc = rs.crc;
+    }
+    uint16_t k_next = 0;
+    ZGPU_HIP_CHECK(hipMemcpyAsync(&hs, e->ct_st, sizeof hs, hipMemcpyDeviceToHost, st));
+    if (ntiles) ZGPU_HIP_CHECK(hipMemcpyAsync(&k_next, e->ct_entry + ntiles, 2, hipMemcpyDeviceToHost, st));
+    if (check_sort) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault, lz_sorted_fault_word(e->par_ws), 4, hipMemcpyDeviceToHost, st));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    collect_spans(e);
+    if (sort_fault) { e->exact_sort = 1; return deflate_cont(e, f, cfg, cs, d_carry_in, res, st); } // (nothing of cs or of the incoming carry has been touched yet)
+    if (hs.overflow) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    // where the stream stands now
+    if (ntiles) {
+        const uint64_t wb_last = w0 + (ntiles - 1) * kTileStride, lim = end - wb_last, h1_last = lim < kTileH1 ? lim : kTileH1;
+        cs->entry = cs->abs0 + wb_last + h1_last + k_next;
+    }
+    if (ends) cs->entry = seg_end;
+    cs->block_start = hs.block_start; cs->carry_ntok = hs.carry_n; cs->data_type = hs.data_type; cs->first_block = hs.first_block; cs->last_eob = hs.last_eob;
+    uint64_t out_bytes;
+    if (f.mode == ZGPU_CONT_FINISH) { out_bytes = (hs.out_bits + 7) >> 3; cs->bit_count = 0; cs->bit_value = 0; } // bi_windup
+    else {
+        out_bytes = hs.out_bits >> 3; cs->bit_count = (uint32_t)(hs.out_bits & 7); cs->bit_value = 0;
+        if (cs->bit_count) {
+            uint8_t last = 0;
+            ZGPU_HIP_CHECK(hipMemcpyAsync(&last, f.d_out + out_bytes, 1, hipMemcpyDeviceToHost, st));
+            ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+            cs->bit_value = last & ((1u << cs->bit_count) - 1u);
+        }
+    }
+    res->out_bytes = out_bytes; res->nchunks = ntiles; res->adler32 = adler; res->crc32 = crc; res->data_type = hs.data_type; res->ntokens = hs.ntokens;
+    return ZGPU_OK;
+}
+
 static int ensure_stage(zgpu_engine *e, uint64_t in_bytes, uint64_t out_bytes)
 {
     if (in_bytes > e->stage_in_cap) {
@@ -523,6 +713,8 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     hipFree(e->hand_list); hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
+    hipFree(e->ct_exits); hipFree(e->ct_entry); hipFree(e->ct_comp); hipFree(e->ct_gentry); hipFree(e->ct_tokoff); hipFree(e->ct_T); hipFree(e->ct_carry); hipFree(e->ct_carry_in); hipFree(e->ct_blk);
+    hipFree(e->ct_pos); hipFree(e->ct_slots); hipFree(e->ct_st); hipFree(e->ct_ckmeta); hipFree(e->ct_excl);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
@@ -570,11 +762,95 @@ int zgpu_deflate_set_tuning(zgpu_engine *e, int on, uint32_t good_length, uint32
     return ZGPU_OK;
 }
 
+// ZGPU_F_CONTINUOUS: the whole input as ONE stream, in one feed that finishes it
+static int deflate_cont_oneshot(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, uint8_t *d_out, uint64_t out_cap, zgpu_deflate_result *res, hipStream_t st)
+{
+    if (!e || !p || !res || (!d_in && in_bytes) || !d_out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    if (p->level < 1 || p->level > 9 || p->strategy < 0 || p->strategy > (int)kFixed) return fail(e, ZGPU_STREAM_ERROR, "level 1..9, strategy 0..4");
+    if (p->prime || (p->flags & (ZGPU_F_POS0 | ZGPU_F_POS0_ALL)) || !(p->flags & ZGPU_F_FINAL) || e->geo_w != 15 || e->geo_m != 8) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: FINAL, no prime, the default geometry");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    LevelCfg cfg = level_cfg(p->level);
+    cfg.strategy = (uint32_t)p->strategy;
+    if (e->tuned) { cfg.good = e->tune[0]; cfg.lazy = e->tune[1]; cfg.nice = e->tune[2]; cfg.chain = (e->tune[3] && e->tune[3] < 0xffffu) ? e->tune[3] : 0xffffu; if (cfg.nice > kMaxMatch) cfg.nice = kMaxMatch; }
+    const bool wrap = p->flags & ZGPU_F_ZLIB_WRAP, gz = p->flags & ZGPU_F_GZIP_WRAP;
+    if (wrap && gz) return fail(e, ZGPU_STREAM_ERROR, "one wrapper at a time");
+    const uint32_t head_bytes = wrap ? 2 : gz ? 10 : 0, tail_bytes = wrap ? 4 : gz ? 8 : 0;
+    if (out_cap < head_bytes + tail_bytes + 8) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    uint8_t hdr[12] = {0};
+    if (wrap) zlib_header(p->level, p->strategy, hdr);
+    if (gz) { const uint8_t h[10] = {31, 139, 8, 0, 0, 0, 0, 0, (uint8_t)(p->level == 9 ? 2 : (p->strategy >= 2 || p->level < 2) ? 4 : 0), 3}; memcpy(hdr, h, 10); }
+    ZGPU_HIP_CHECK(hipMemcpyAsync(d_out, hdr, (head_bytes + 4) & ~3u, hipMemcpyHostToDevice, st)); // (zero-filled to a whole word: the first block's bits are ORed in behind the header)
+    ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+    zgpu_cont_state cs{}; cs.data_type = 2; cs.first_block = 1; cs.last_eob = 8;
+    ContFeed f{}; f.d_buf = d_in; f.buf_bytes = in_bytes; f.check_from = 0; f.mode = ZGPU_CONT_FINISH; f.d_out = d_out; f.out_cap = out_cap - tail_bytes; f.prefix_bits = 8ull * head_bytes;
+    f.want_crc = gz || (p->flags & ZGPU_F_CRC32);
+    int rc = ensure_cont_ws(e, 1, 1);
+    if (rc) return rc;
+    rc = deflate_cont(e, f, cfg, &cs, e->ct_carry_in, res, st);
+    if (rc) return rc;
+    if (wrap) {
+        const uint32_t a = res->adler32;
+        uint8_t tr[4] = {(uint8_t)(a >> 24), (uint8_t)(a >> 16), (uint8_t)(a >> 8), (uint8_t)a};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_out + res->out_bytes, tr, 4, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        res->out_bytes += 4;
+    }
+    if (gz) {
+        const uint32_t c = res->crc32, isz = (uint32_t)in_bytes;
+        uint8_t tr[8] = {(uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24), (uint8_t)isz, (uint8_t)(isz >> 8), (uint8_t)(isz >> 16), (uint8_t)(isz >> 24)};
+        ZGPU_HIP_CHECK(hipMemcpyAsync(d_out + res->out_bytes, tr, 8, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        res->out_bytes += 8;
+    }
+    if (!f.want_crc) res->crc32 = 0;
+    return ZGPU_OK;
+}
+
+uint64_t zgpu_deflate_cont_bound(uint64_t in_bytes)
+{
+    // deflateBound's own arithmetic for a stream whose blocks may not be stored (deflate.c:513-515) plus a word per block boundary and the framing:
+    // what a feed of in_bytes can write
+    return in_bytes + ((in_bytes + 7) >> 3) + ((in_bytes + 63) >> 6) + 5 * (in_bytes / 16383 + 2) + 64;
+}
+
+int zgpu_deflate_cont_host(zgpu_engine *e, const void *buf, uint64_t buf_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode, zgpu_cont_state *cs,
+                           uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res)
+{
+    if (!e || !p || !res || !cs || !carry_tok || (!buf && buf_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    if (p->level < 1 || p->level > 9 || p->strategy < 0 || p->strategy > (int)kFixed || mode < ZGPU_CONT_MORE || mode > ZGPU_CONT_FINISH) return fail(e, ZGPU_STREAM_ERROR, "level 1..9, strategy 0..4, a ZGPU_CONT_* mode");
+    if (e->geo_w != 15 || e->geo_m != 8) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: the default geometry");
+    ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    LevelCfg cfg = level_cfg(p->level);
+    cfg.strategy = (uint32_t)p->strategy;
+    if (e->tuned) { cfg.good = e->tune[0]; cfg.lazy = e->tune[1]; cfg.nice = e->tune[2]; cfg.chain = (e->tune[3] && e->tune[3] < 0xffffu) ? e->tune[3] : 0xffffu; if (cfg.nice > kMaxMatch) cfg.nice = kMaxMatch; }
+    const uint64_t bound = zgpu_deflate_cont_bound(buf_bytes) + kContCarry * 4;
+    int rc = ensure_stage(e, buf_bytes, bound);
+    if (rc) return rc;
+    if ((rc = ensure_cont_ws(e, 1, 1))) return rc;
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (buf_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, buf, buf_bytes, hipMemcpyHostToDevice, e->stream));
+    if (cs->carry_ntok) ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_carry_in, carry_tok, (size_t)cs->carry_ntok * 4, hipMemcpyHostToDevice, e->stream));
+    const uint32_t first_word = cs->bit_value & ((1u << cs->bit_count) - 1u);
+    ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_out, &first_word, 4, hipMemcpyHostToDevice, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    ContFeed f{}; f.d_buf = e->stage_in; f.buf_bytes = buf_bytes; f.check_from = check_from; f.mode = mode; f.h_excl = excl; f.nexcl = nexcl;
+    f.d_out = e->stage_out; f.out_cap = bound; f.prefix_bits = cs->bit_count; f.want_crc = (p->flags & ZGPU_F_CRC32) != 0;
+    rc = deflate_cont(e, f, cfg, cs, e->ct_carry_in, res, e->stream);
+    if (rc) return rc;
+    if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+    if (res->out_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (cs->carry_ntok) ZGPU_HIP_CHECK(hipMemcpyAsync(carry_tok, e->ct_carry, (size_t)cs->carry_ntok * 4, hipMemcpyDeviceToHost, e->stream));
+    ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (!f.want_crc) res->crc32 = 0;
+    return ZGPU_OK;
+}
+
 int zgpu_deflate_device(zgpu_engine *e, const void *d_in, uint64_t in_bytes, const zgpu_deflate_params *p, void *d_out, uint64_t out_cap,
                         uint64_t *d_chunk_offsets, zgpu_deflate_result *res, void *hip_stream)
 {
     if (!e) return ZGPU_STREAM_ERROR;
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->stream;
+    if (p && (p->flags & ZGPU_F_CONTINUOUS)) return deflate_cont_oneshot(e, static_cast<const uint8_t *>(d_in), in_bytes, p, static_cast<uint8_t *>(d_out), out_cap, res, st);
     return deflate_device(e, static_cast<const uint8_t *>(d_in), in_bytes, nullptr, 0, p, static_cast<uint8_t *>(d_out), out_cap, d_chunk_offsets, res, st);
 }
 
@@ -602,6 +878,19 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
 {
     if (!e || !p || !res || (!in && in_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
+    if (p->flags & ZGPU_F_CONTINUOUS) { // one continuous stream: staged whole, compressed in one feed
+        const uint64_t cb = zgpu_deflate_cont_bound(in_bytes) + 32;
+        int rc2 = ensure_stage(e, in_bytes, cb);
+        if (rc2) return rc2;
+        ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+        rc2 = deflate_cont_oneshot(e, e->stage_in, in_bytes, p, e->stage_out, cb, res, e->stream);
+        if (rc2) return rc2;
+        if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
+        ZGPU_HIP_CHECK(hipMemcpyAsync(out, e->stage_out, res->out_bytes, hipMemcpyDeviceToHost, e->stream));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
+        return ZGPU_OK;
+    }
     const uint32_t chunk_size = p->chunk_size ? p->chunk_size : kChunkMax;
     const uint64_t bound = zgpu_deflate_bound_geometry(in_bytes, chunk_size, e ? e->geo_w : 15, e ? e->geo_m : 8);
     int rc = ensure_stage(e, in_bytes, bound);

@@ -507,7 +507,12 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_huf_time(unsig
 #ifndef ZGPU_HUF_WAVES
 #define ZGPU_HUF_WAVES 8 // waves per SIMD the register budget is cut for (A/B builds: -DZGPU_HUF_WAVES=n; 6 and 7 spill less and keep fewer chunks resident)
 #endif
-__global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees)
+// CONT (continuous stream, zgpu_cont.hip): the workgroup codes ONE block -- blk[blockIdx.x], its tokens a run of the batch's compact token array -- into a
+// slot of its own from bit 0; where the block starts in the stream (a bit position that depends on every block in front of it) is the stitcher's business,
+// and so are the bytes of a stored block (copied from the input there); the block's size, type and last_eob_len go back into blk[].
+template <bool CONT>
+__global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(ChunkGeom g, const uint32_t *__restrict__ tokens, ChunkMeta *meta, uint8_t *slots, uint32_t fixed_trees,
+                                                                            ContBlk *blk, ContState *cst)
 {
     __shared__ __attribute__((aligned(16))) TreeWork work0;
     __shared__ TreeWorkD work1;
@@ -525,18 +530,18 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
     __shared__ uint32_t sh_carry; // the bits of the word at sh_bitpos that are not in memory yet (BitWriter)
 
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    if (c >= g.nchunks) return;
-    uint64_t lo; uint32_t nbytes;
-    chunk_span(g, c, lo, nbytes);
+    if (!CONT && c >= g.nchunks) return;
+    uint64_t lo = 0; uint32_t nbytes = 0;
+    if (!CONT) chunk_span(g, c, lo, nbytes);
     const uint8_t *src = g.in + lo;
-    const uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t *tok = CONT ? tokens + blk[c].tok0 : tokens + (size_t)c * kChunkMax;
     uint32_t *out = reinterpret_cast<uint32_t *>(slots + (size_t)c * g.slot_stride);
-    const uint32_t ntok = meta[c].ntok, nostore = meta[c].nostore;
-    const bool final_chunk_here = chunk_is_final(g, c);
-    const uint32_t btok = g.block_tokens, nblocks = ntok / btok + ((nostore & kFullFinalBlock) ? 0u : 1u); // (a last block filled by deflate_slow's trailing literal has no empty block behind it)
-    const uint32_t *nostore_bits = g.nostore_bits ? g.nostore_bits + (size_t)c * kGeoNostoreWords : nullptr;
-    uint32_t block_start = chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
-    if (tid == 0) { const uint32_t pr = chunk_prime(g, c); sh_bitpos = pr >> 16; sh_carry = pr & 0xffffu; } // (deflatePrime: bi_valid and bi_buf as the first block finds them, deflate.c:411-412)
+    const uint32_t ntok = CONT ? blk[c].nt : meta[c].ntok, nostore = CONT ? blk[c].nostore : meta[c].nostore;
+    const bool final_chunk_here = CONT ? blk[c].eof != 0 : chunk_is_final(g, c);
+    const uint32_t btok = g.block_tokens, nblocks = CONT ? 1u : ntok / btok + ((nostore & kFullFinalBlock) ? 0u : 1u); // (a last block filled by deflate_slow's trailing literal has no empty block behind it)
+    const uint32_t *nostore_bits = (!CONT && g.nostore_bits) ? g.nostore_bits + (size_t)c * kGeoNostoreWords : nullptr;
+    uint32_t block_start = CONT ? 0u : chunk_skip(g, c), data_type = 2; // (behind a preset dictionary)
+    if (tid == 0) { const uint32_t pr = CONT ? 0u : chunk_prime(g, c); sh_bitpos = pr >> 16; sh_carry = pr & 0xffffu; } // (deflatePrime: bi_valid and bi_buf as the first block finds them, deflate.c:411-412)
     HUF_T0();
 
     for (uint32_t b = 0; b < nblocks; b++) {
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
         __syncthreads();
         if (tid == 0) hist[kEndBlock] = 1;
         __syncthreads();
-        if (b == 0 && stored_len > 0) { // set_data_type, trees.c:1126-1139 (first block of the stream decides)
+        if ((CONT ? blk[c].first != 0 : b == 0) && stored_len > 0) { // set_data_type, trees.c:1126-1139 (first block of the stream decides)
             bool bin = false;
             if (tid < 32 && (tid < 9 || tid >= 14)) bin = hist[tid] != 0;
             data_type = __syncthreads_or(bin) ? 0u : 1u;
@@ -646,7 +651,15 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
         HUF_T(3);
         const uint32_t btype = sh_btype;
         uint64_t bitpos = sh_bitpos;
-        if (btype == 0) {
+        if (CONT) {
+            if (tid == 0) { // (the slot holds a coded block from bit 0; a stored block's bytes are taken from the input by the stitcher)
+                ContBlk &o = blk[c];
+                o.btype = btype; o.stored_len = stored_len; o.eob_len = btype == 0 ? 8u : btype == 1 ? 7u : (uint32_t)llen[kEndBlock];
+                if (o.first) cst->data_type = data_type;
+            }
+        }
+        if (btype == 0 && CONT) { }
+        else if (btype == 0) {
             uint8_t *dst = reinterpret_cast<uint8_t *>(out) + (bitpos >> 3);
             if (tid == 0) { // the header's last bytes, still in the carry (the stored bytes follow them inside the same word)
                 const uint32_t k = (uint32_t)(bitpos >> 3) & 3u, cw = sh_carry;
@@ -720,7 +733,9 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (CONT) {
+        if (tid == 0) { BitWriter bw; bw.begin(out, sh_bitpos, sh_carry); bw.store_tail(); blk[c].nbits = (uint32_t)sh_bitpos; }
+    } else if (tid == 0) {
         BitWriter bw; bw.begin(out, sh_bitpos, sh_carry);
         if (!final_chunk_here) { bw.put(0, 3); bw.align_byte(); bw.put(0, 16); bw.put(0xffff, 16); } // flush marker
         else bw.align_byte();                                                                        // bi_windup
@@ -734,7 +749,12 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
 
 void launch_huffman(const ChunkGeom &g, const uint32_t *tokens, ChunkMeta *meta, uint8_t *slots, hipStream_t st, bool fixed_trees)
 {
-    hipLaunchKernelGGL(huffman_kernel, dim3(g.nchunks), dim3(kThreads), 0, st, g, tokens, meta, slots, fixed_trees ? 1u : 0u);
+    hipLaunchKernelGGL(huffman_kernel<false>, dim3(g.nchunks), dim3(kThreads), 0, st, g, tokens, meta, slots, fixed_trees ? 1u : 0u, nullptr, nullptr);
+}
+// the blocks of a continuous stream's batch: g carries block_tokens and slot_stride only
+void launch_huffman_cont(const ChunkGeom &g, const uint32_t *compact_tokens, uint32_t nblk, ContBlk *blk, ContState *cst, uint8_t *slots, hipStream_t st, bool fixed_trees)
+{
+    if (nblk) hipLaunchKernelGGL(huffman_kernel<true>, dim3(nblk), dim3(kThreads), 0, st, g, compact_tokens, nullptr, slots, fixed_trees ? 1u : 0u, blk, cst);
 }
 
 } // namespace zgpu

@@ -750,14 +750,88 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_time(unsi
 #endif
 __device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
 
+// TILE (continuous stream): where the parse leaves the tile as a function of where it enters it.  The games the walkers have played (gm, one bit per game
+// start in gs) are a forest over the positions [h0, h1): a game started at r ends in the neutral position q = m + len, literals follow up to the next game
+// start.  Every possible entry h0 + k is the start of a walker, so the path from it lies in the forest.  Game starts are numbered (prefix counts of gs), the
+// successor of each is looked up, and pointer jumping (N[i] = N[N[i]], in place) takes every start to the exit of its path in log2(depth) rounds: no serial
+// walk through the tile.  exits[k] = (neutral position the parse entered at h0 + k ends in) - h1, 0 .. 512.  T lanes, LDS from `pl` (the chunk bytes are dead).
+template <uint32_t T>
+__device__ inline void tile_exits(uint8_t *pl, const uint32_t *gm, const uint32_t *gs, uint32_t h0, uint32_t h1, uint32_t nent, uint16_t *exits, uint32_t tid)
+{
+    constexpr uint32_t kWords = kChunkMax / 32;
+    static_assert(kWords % T == 0 && T % 64 == 0 && T <= 1024, "workgroup size");
+    uint32_t *HAS = reinterpret_cast<uint32_t *>(pl);
+    uint16_t *wcnt = reinterpret_cast<uint16_t *>(pl + kWords * 4);
+    uint32_t *wtot = reinterpret_cast<uint32_t *>(pl + kWords * 6);
+    uint16_t *N = reinterpret_cast<uint16_t *>(pl + kWords * 6 + 64);
+    static_assert(kWords * 6 + 64 + (kTileH1 / 3 + 2) * 2 <= kM3DataLds, "the successor table fits the chunk's LDS");
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    constexpr uint32_t per = kWords / T;
+    uint32_t sum = 0, cnt[per];
+#pragma unroll
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t w = tid * per + i, v = __hip_atomic_load(gs + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        HAS[w] = v; cnt[i] = (uint32_t)__builtin_popcount(v); sum += cnt[i];
+    }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+    if (lane == 63) wtot[wave] = x;
+    __syncthreads();
+    uint32_t b = x - sum;
+    for (uint32_t w = 0; w < wave; w++) b += wtot[w];
+#pragma unroll
+    for (uint32_t i = 0; i < per; i++) { wcnt[tid * per + i] = (uint16_t)b; b += cnt[i]; }
+    __syncthreads();
+    uint32_t nn = 0;
+    for (uint32_t w = 0; w < T / 64; w++) nn += wtot[w]; // game starts of the tile
+    auto rank_of = [&](uint32_t p) { return (uint32_t)wcnt[p >> 5] + (uint32_t)__builtin_popcount(HAS[p >> 5] & ~(~0u << (p & 31u))); };
+    constexpr uint32_t kExit = 0x8000u; // N[i] = kExit | (exit - h1), or the number of the next game start on the path
+    for (uint32_t p0 = h0 & ~31u; p0 < h1; p0 += T * 8) {
+        uint32_t gv[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { const uint32_t p = p0 + u * T + tid; gv[u] = p < h1 ? __hip_atomic_load(gm + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; } // (all of them: loads under a per-lane condition are waited for one by one)
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t p = p0 + u * T + tid;
+            if (p < h1 && ((HAS[p >> 5] >> (p & 31u)) & 1u)) {
+                const uint32_t q = p + (gv[u] >> 24) + ((gv[u] >> 15) & 511u);
+                uint32_t v = kExit | (q > h1 ? q - h1 : 0u);
+                if (q < h1) { const uint32_t t = next_bit(HAS, q, kWords); if (t != kNone && t < h1) v = rank_of(t); }
+                N[rank_of(p)] = (uint16_t)v;
+            }
+        }
+    }
+    __syncthreads();
+    for (;;) {
+        bool more = false;
+        for (uint32_t i = tid; i < nn; i += T) {
+            const uint32_t v = N[i];
+            if (!(v & kExit)) { const uint32_t w = N[v]; N[i] = (uint16_t)w; more = more || !(w & kExit); } // (another lane may move N[v] on meanwhile: old or new, both lie further down i's path)
+        }
+        if (!__syncthreads_or(more)) break;
+    }
+    for (uint32_t k = tid; k < kTileExitStride; k += T) {
+        uint32_t v = 0;
+        if (k < nent) {
+            const uint32_t e = h0 + k, t = e < h1 ? next_bit(HAS, e, kWords) : kNone;
+            v = (t == kNone || t >= h1) ? (e > h1 ? e - h1 : 0u) : ((uint32_t)N[rank_of(t)] & 0x7fffu);
+        }
+        exits[k] = (uint16_t)v;
+    }
+}
+
 // FUSE: when its walkers are done the workgroup goes on with the rest of the parse itself (parse_chunk, zgpu_lz_parse.h, in the LDS the
 // chunk bytes lived in).  That part is all latency -- a window at a time, one wave threading the path -- and leaves the CU's vector
 // units to the other workgroup's walkers, which are bound by exactly those; as a kernel of its own it cost as much as a third of the walk.
 static_assert(kP2LdsBytes <= kM3DataLds, "the parse works in the memory of the chunk bytes");
-template <bool FUSE>
+// MODE 0: the walkers alone; 1: the rest of the parse behind them (FUSE); 2: a TILE of a continuous stream (zgpu_cont.hip) -- walkers start at every possible
+// entry of the tile and at every 64th position of its range [h0, h1), stop at h1, and the workgroup ends with the tile's exit as a function of its entry.
+template <int MODE>
 __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkGeom g, LevelCfg cfg, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
-                                                            uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all, uint32_t *__restrict__ tokens, ChunkMeta *meta)
+                                                            uint32_t *__restrict__ gm_all, uint32_t *__restrict__ gs_all, uint32_t *__restrict__ tokens, ChunkMeta *meta, TileGeom tg)
 {
+    constexpr bool FUSE = MODE == 1, TILE = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *d32 = lds;
     uint32_t *ctrl = lds + kM3DataLds / 4; // [0]: next block to hand out
@@ -771,7 +845,17 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
     const uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
     const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
     uint32_t *gm = gm_all + (size_t)c * kChunkMax, *gs = gs_all + (size_t)c * (kChunkMax / 32);
-    const uint32_t npos = n >= 3 ? n - 2 : 0, base = chunk_base(g, c);
+    uint32_t th0 = 0, th1 = n, tnent = 0, tnent_all = 0, nil_local = ~0u; // TILE: the range the tile parses, its entries, the position whose first candidate at MAX_DIST is NIL
+    uint32_t base = chunk_base(g, c);
+    if (TILE) {
+        uint64_t wb; uint32_t nl;
+        tile_span(g, tg, c, wb, nl, th0, th1, tnent);
+        tnent_all = tnent;
+        if (tnent > th1 - th0) tnent = th1 - th0; // (walkers start inside the range only; an entry at or behind h1 passes the tile by)
+        base = (tg.abs0_nil && tg.abs0 + wb == 0) ? 0u : 1u; // only the stream's own position 0 is NIL; a tile's local 0 is out of every parsed position's reach
+        if (tg.nil_pos >= wb && tg.nil_pos - wb < kChunkMax) nil_local = (uint32_t)(tg.nil_pos - wb);
+    }
+    const uint32_t npos = n >= 3 ? n - 2 : 0;
     stage_chunk<kWThreads>(src, n, d32, tid);
     for (uint32_t i = tid; i < kChunkMax / 32; i += kWThreads) { if (i < kWNeuBytes / 4) NEU[i] = 0; gs[i] = 0; }
     if (tid < 8) d32[(kChunkMax + 64) / 4 + tid] = 0xffffffffu; // the word the quick check reads where a zero word would look like a hit
@@ -783,7 +867,9 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         const int a = b0 - (int)kMinLookahead + 1, b = (int)(kWSize + kMaxDist) - (int)base;
         slide_at = a > b ? a : b;
     }
-    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = (n + kWBlk - 1) / kWBlk;
+    // blocks: TILE -- one per entry, then one per 64 positions of the rest of the range
+    const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = TILE ? tnent + (th1 - th0 - tnent + kWBlk - 1) / kWBlk : (n + kWBlk - 1) / kWBlk;
+    const uint32_t wlim = TILE ? th1 : n; // a walker that arrives here, neutral, is done with the chunk / the tile
     const uint32_t lanebits = lane << 16, dummy = ring + (kRing - 1) * 4;
     // walker
     uint32_t st = W_NEED, x = 0, handL = kMinMatch - 1, handM = 0, handD = 0, gstart = 0;
@@ -875,7 +961,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         }
         if (toN) { // neutral at y
             st = W_NEED;
-            if (y < n) {
+            if (y < wlim) {
                 const uint32_t yc = y >> kWNeuShift, bit = 1u << (yc & 31u);
                 const bool meet = (y & ((1u << kWNeuShift) - 1u)) == 0; // (elsewhere walkers pass each other unseen: the same work twice, the same result)
                 if (!meet || !(atomicOr(&NEU[yc >> 5], bit) & bit)) { // nobody has been here: go on
@@ -897,7 +983,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
                     const uint32_t b = b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0));
                     if (b >= nblk) st = W_DONE;
                     else {
-                        const uint32_t y2 = b * kWBlk, bit = 1u << ((y2 >> kWNeuShift) & 31u);
+                        const uint32_t y2 = TILE ? (b < tnent ? th0 + b : th0 + tnent + (b - tnent) * kWBlk) : b * kWBlk, bit = 1u << ((y2 >> kWNeuShift) & 31u);
                         if (!(atomicOr(&NEU[(y2 >> kWNeuShift) >> 5], bit) & bit)) { x = y2; handL = kMinMatch - 1; irl = y2 < npos ? ir[y2] : 0; st = W_LIMBO; }
                         // (else: a walker from further down passed through here; the next pass asks for another block)
                     }
@@ -912,7 +998,12 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
             irn = x + 1 < npos ? ir[x + 1] : 0;
             if (seed >= kMinMatch) { const uint32_t E = handM + handL; irE = E < npos ? ir[E] : 0; haveE = true; }
             // the one position whose first candidate can sit at window index 32768: NIL after the slide (deflate.c:1309-1312)
-            if (x + base == kWSize + kMaxDist && avail != 0 && (int)x >= slide_at && (uint32_t)S[idx - 1] + base == kWSize) avail = 0;
+            if (TILE) {
+                if (x == nil_local && avail != 0 && x - (uint32_t)S[idx - 1] == kMaxDist) avail = 0;
+                if (cfg.strategy == kHuffmanOnly) avail = 0;                                                            // deflate.c:1594: no search at all
+                if (cfg.strategy == kRle && avail != 0) avail = x - (uint32_t)S[idx - 1] == 1 ? 1u : 0u;                // deflate.c:1596-1599: the nearest candidate, at distance 1 only
+            }
+            else if (x + base == kWSize + kMaxDist && avail != 0 && (int)x >= slide_at && (uint32_t)S[idx - 1] + base == kWSize) avail = 0;
             best = seed; sentinel = (seed << 16) | 0xffffu; key_seen = sentinel; boff = dbase + best - 1;
             scan2 = (uint32_t)d8[x + best - 1] | ((uint32_t)d8[x + best] << 16);
             lds_st32(slot + lane * 4, sentinel);
@@ -1002,10 +1093,14 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         }
         W_T(1);
     }
+    if (TILE) {
+        __syncthreads(); // every walker of the tile is done: gm / gs are complete
+        tile_exits<kWThreads>(reinterpret_cast<uint8_t *>(lds), gm, gs, th0, th1, tnent_all, tg.exits + (size_t)c * kTileExitStride, tid);
+    }
     if (FUSE) {
         __syncthreads(); // every walker of the chunk is done: gm / gs are complete (and written: the barrier waits for the stores)
         constexpr uint32_t kP2Threads = kWThreads;
-        constexpr bool LITE = true, FUSED = true;
+        constexpr bool LITE = true, FUSED = true, TILE = false;
         const uint2 *recs = nullptr;
         const uint32_t *gmv_all = gm_all, *gsv_all = gs_all;
         uint8_t *pl = reinterpret_cast<uint8_t *>(lds);
@@ -1013,7 +1108,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         uint32_t *const HAS = reinterpret_cast<uint32_t *>(pl + kP2OffHAS), *const MARK = reinterpret_cast<uint32_t *>(pl + kP2OffMARK), *const COV = reinterpret_cast<uint32_t *>(pl + kP2OffCOV),
                  *const MAT = reinterpret_cast<uint32_t *>(pl + kP2OffMAT), *const wbase = reinterpret_cast<uint32_t *>(pl + kP2OffWbase), *const VIS = reinterpret_cast<uint32_t *>(pl + kP2OffVIS),
                  *const EXITS = reinterpret_cast<uint32_t *>(pl + kP2OffEXITS), *const wave_tot = reinterpret_cast<uint32_t *>(pl + kP2OffWtot);
-        uint32_t &sh_entry = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry);
+        uint32_t &sh_entry = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry), &sh_exit = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry + 4);
 #include "zgpu_lz_parse_body.inc"
     }
 }
@@ -1270,16 +1365,16 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
         if (fuse < 0) { const char *v = getenv("ZGPU_WALK_FUSE"); fuse = v ? atoi(v) : 1; }
         static bool opt_inw = false;
         if (!opt_inw) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds);
             opt_inw = true;
         }
         if (fuse) {
-            hipLaunchKernelGGL(walk_kernel<true>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
+            hipLaunchKernelGGL(walk_kernel<1>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta, TileGeom{});
             prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
             return adler_done;
         }
-        hipLaunchKernelGGL(walk_kernel<false>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta);
+        hipLaunchKernelGGL(walk_kernel<0>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta, TileGeom{});
         prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
         prof_span_begin(prof, st, &ev);
         launch_parse_lite(g, cfg, gm, gs, tokens, meta, st);
@@ -1295,6 +1390,44 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
 
     prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
     return adler_done;
+}
+
+// A batch of tiles of a continuous stream (zgpu_cont.hip): sort, walkers + exit functions, the chain of entries, the tiles' tokens.
+void launch_chain(const uint16_t *exits, uint32_t ntiles, uint16_t *comp, uint16_t *gentry, uint16_t *entry, hipStream_t st);
+void launch_parse_tile(const ChunkGeom &g, LevelCfg cfg, const uint32_t *gm, const uint32_t *gs, uint32_t *tokens, ChunkMeta *meta, const TileGeom &tg, hipStream_t st);
+void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, uint16_t *comp, uint16_t *gentry, hipStream_t st,
+                     void *prof, int exact_sort)
+{
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    const size_t nch = g.nchunks;
+    uint32_t *fault = reinterpret_cast<uint32_t *>(w);
+    uint16_t *S = reinterpret_cast<uint16_t *>(w + 256);
+    uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
+    uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
+    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * kHeadStride);
+    uint32_t *ir = reinterpret_cast<uint32_t *>(recs + nch * kChunkMax);
+    uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
+    hipEvent_t ev{};
+    prof_span_begin(prof, st, &ev);
+    static int sort_env = -1;
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (exact_sort || sort_env == 1) {
+        hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
+        hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
+    } else {
+        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st);
+    }
+    prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
+    prof_span_begin(prof, st, &ev);
+    static bool opt_in = false;
+    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWLds); opt_in = true; }
+    hipLaunchKernelGGL(walk_kernel<2>, dim3(g.nchunks), dim3(kWThreads), kWLds, st, g, cfg, S, ir, gm, gs, tokens, meta, tg);
+    prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
+    prof_span_begin(prof, st, &ev);
+    launch_chain(tg.exits, g.nchunks, comp, gentry, tg.entry + g.chunk0, st);
+    launch_parse_tile(g, cfg, gm, gs, tokens, meta, tg, st);
+    prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
 }
 
 // the word sort3's pass V raises (first word of the workspace)

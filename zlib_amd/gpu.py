@@ -5,7 +5,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL, F_GZIP_WRAP, F_CRC32 = 1, 2, 4, 8, 16, 32
+F_FINAL, F_ZLIB_WRAP, F_POS0, F_POS0_ALL, F_GZIP_WRAP, F_CRC32, F_CONTINUOUS = 1, 2, 4, 8, 16, 32, 64
+CONT_MORE, CONT_FLUSH, CONT_FINISH = 0, 1, 2  # zgpu_deflate_cont_host modes
 WHOLE_STREAM = 0xFFFFFFFF  # inflate chunk_size: the one segment is a complete stream of any size
 LZ_AUTO, LZ_SERIAL, LZ_PARALLEL, LZ_SORTED, LZ_WALK, LZ_FAST, LZ_FASTWIN = 0, 1, 2, 3, 4, 5, 6
 CHECK_ADLER32, CHECK_CRC32 = 1, 2  # zgpu_inflate_set_checks
@@ -27,6 +28,12 @@ class _Params(C.Structure):
 class DeflateResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("nchunks", C.c_uint64), ("adler32", C.c_uint32), ("data_type", C.c_uint32),
                 ("ntokens", C.c_uint64), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ContState(C.Structure):
+    """zgpu_cont_state: where a continuous stream stands between two feeds (stream positions)."""
+    _fields_ = [("abs0", C.c_uint64), ("entry", C.c_uint64), ("block_start", C.c_uint64), ("carry_ntok", C.c_uint32), ("bit_count", C.c_uint32),
+                ("bit_value", C.c_uint32), ("data_type", C.c_uint32), ("first_block", C.c_uint32), ("last_eob", C.c_uint32)]
 
 
 class InflateResult(C.Structure):
@@ -71,6 +78,9 @@ def load_library():
     L.zgpu_deflate_set_geometry.argtypes = [vp, C.c_int, C.c_int]
     L.zgpu_deflate_device.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
+    L.zgpu_deflate_cont_bound.argtypes = [u64]
+    L.zgpu_deflate_cont_bound.restype = u64
+    L.zgpu_deflate_cont_host.argtypes = [vp, vp, u64, u64, C.POINTER(_Params), C.c_int, C.POINTER(ContState), vp, vp, u32, vp, u64, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_host.argtypes = [vp, vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
@@ -163,6 +173,8 @@ class Engine:
         arr = np.frombuffer(data, dtype=np.uint8) if not hasattr(data, "ctypes") else data
         n = int(arr.size)
         cap = self.L.zgpu_deflate_bound_geometry(n, chunk_size, *getattr(self, "geometry", (15, 8)))
+        if flags & F_CONTINUOUS:
+            cap = self.L.zgpu_deflate_cont_bound(n) + 32
         out = np.empty(cap, dtype=np.uint8)
         nchunks = max(1, (n + chunk_size - 1) // chunk_size)
         offs = np.zeros(nchunks + 1, dtype=np.uint64)
@@ -174,6 +186,28 @@ class Engine:
         self.last = res
         z = out[: res.out_bytes].tobytes()
         return (z, offs) if want_offsets else z
+
+    def cont_new(self):
+        """State of a fresh continuous stream (no dictionary) + its token carry."""
+        import numpy as np
+        cs = ContState(0, 0, 0, 0, 0, 0, 2, 1, 8)
+        return cs, np.zeros(16384, dtype=np.uint32)
+
+    def deflate_cont_host(self, buf, check_from, level, mode, cs, carry, strategy=0, flags=0, excl=()):
+        """One feed of a continuous stream (zgpu_deflate_cont_host): buf = the history the parse can still reach + the unparsed bytes, buf[0] at stream
+        position cs.abs0.  Returns the whole bytes the feed wrote; cs and carry move on.  self.last has the checksums of buf[check_from:]."""
+        import numpy as np
+        arr = np.frombuffer(bytes(buf) + b"\0", dtype=np.uint8)
+        n = int(arr.size) - 1
+        cap = self.L.zgpu_deflate_cont_bound(n) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        p = _Params(level, 0, flags, LZ_AUTO, strategy, 0)
+        res = DeflateResult()
+        ex = np.ascontiguousarray(list(excl) + [0], dtype=np.uint64)
+        self._check(self.L.zgpu_deflate_cont_host(self.h, arr.ctypes.data, n, check_from, C.byref(p), mode, C.byref(cs), carry.ctypes.data,
+                                                  ex.ctypes.data, len(excl), out.ctypes.data, cap, C.byref(res)))
+        self.last = res
+        return out[: res.out_bytes].tobytes()
 
     def set_geometry(self, window_bits=15, mem_level=8):
         """deflateInit2's windowBits (9..15) and memLevel (1..9) for the deflate calls that follow; 15 / 8 is the default."""
