@@ -109,6 +109,14 @@ struct TileGeom {
     uint16_t *exits;   // [tile of the launch][kTileExitStride]
     uint16_t *entry;   // [tile of the feed]: where the parse enters the tile, relative to its h0
 };
+// is buffer offset `at` one of the positions that are not in the hash chains (ChunkGeom::excl, ascending)?  lower bound of `at` in the list
+__device__ inline uint32_t excl_lower(const ChunkGeom &g, uint64_t at)
+{
+    uint32_t lo = 0, hi = g.nexcl;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (g.excl[mid] < at) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ inline bool excl_has(const ChunkGeom &g, uint64_t at) { const uint32_t i = excl_lower(g, at); return i < g.nexcl && g.excl[i] == at; }
 __device__ inline void tile_span(const ChunkGeom &g, const TileGeom &tg, uint32_t c, uint64_t &wb, uint32_t &nloc, uint32_t &h0, uint32_t &h1, uint32_t &nent)
 {
     const uint64_t ti = g.chunk0 + c;

@@ -592,7 +592,7 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
         const uint64_t seg_here = (ends && last_batch) ? seg_end : ~0ull;
         {
             StageTimer t(e, st, ZGPU_STAGE_PARSE);
-            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, st);
+            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH && seg_here != ~0ull, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, st);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);

@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(kThreads, ZGPU_HUF_WAVES) huffman_kernel(Chunk
 
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
     if (!CONT && c >= g.nchunks) return;
+    if (CONT && c >= cst->nblk) return; // (the launch is sized for the most blocks the batch can have)
     uint64_t lo = 0; uint32_t nbytes = 0;
     if (!CONT) chunk_span(g, c, lo, nbytes);
     const uint8_t *src = g.in + lo;

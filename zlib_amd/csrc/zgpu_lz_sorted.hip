@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
         for (uint32_t st = 0; st < kSuperS / 64; st++) {
             const uint32_t o = st * 64 + lane, p = base_p + o;
             const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]);
-            const bool live = p < npos && (h & (kSortWaves - 1)) == wave; // this wave owns its share of the hash space
+            const bool out = g.nexcl != 0 && p < npos && excl_has(g, lo + p); // (continuous stream: a position in front of an earlier flush point is in no chain)
+            const bool live = p < npos && !out && (h & (kSortWaves - 1)) == wave; // this wave owns its share of the hash space
             uint32_t old = 0;
             if (live) old = vcnt[h];
             // lanes of this step that share a hash: detected through a small tag table (a false alarm is harmless; the
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
             }
             if (live && last) vcnt[h] = (uint16_t)(old + group);
             if (live) out_stage[o] = (uint16_t)rank;
-            else if (p >= npos && wave == 0) out_stage[o] = 0;
+            else if ((p >= npos || out) && wave == 0) out_stage[o] = out ? 0xffffu : 0;
         }
         __syncthreads();
     }
@@ -208,6 +209,7 @@ __global__ void __launch_bounds__(kSortThreads) sort_kernel(ChunkGeom g, uint16_
             const uint32_t o = st * kSortThreads + tid, p = base_p + o;
             if (p < npos) {
                 const uint32_t h = hash3(s8[o], s8[o + 1], s8[o + 2]), r = rk[p], id = (uint32_t)cnt[h] + r;
+                if (r == 0xffffu) continue; // not in the chains
                 S[id] = (uint16_t)p;
                 ir[p] = id | (r << 16);
                 if (r == 0) atomicOr(&hd[id >> 5], 1u << (id & 31u)); // bucket head
@@ -262,6 +264,8 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     if (threadIdx.x < kSPad) S[-(int)kSPad + (int)threadIdx.x] = 0; // the pad reads as "position 0" (match3's finished lanes)
     uint32_t last_of_half0 = 0;
     const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
+    // continuous stream: positions in front of earlier flush points have three bytes but are in no chain: no rank, no place in S (marker 0xffff in rk)
+    const uint32_t nout = g.nexcl ? excl_lower(g, lo + npos) - excl_lower(g, lo) : 0u, nin = npos - nout;
     const uint32_t cnt_a = lds_off(cnt), tok_a = lds_off(&token);
     {
         uint4 *z = reinterpret_cast<uint4 *>(cnt);
@@ -286,6 +290,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
             for (uint32_t u = 0; u < kS3TurnSteps; u++) {
                 const uint32_t p = T * kS3TurnPos + 64 * u + lane, v = p < npos ? bytes3(p) : 0u;
                 hv[u] = p < npos ? hash_of(v) : ~0u;
+                if (nout && p < npos && excl_has(g, lo + p)) { hv[u] = ~0u; rk[p] = 0xffffu; }
                 s1 += v & 255u; s2 += (n - p) * (v & 255u);
             }
         };
@@ -364,7 +369,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
 #pragma unroll
         for (uint32_t u = 0; u < kS3Batch; u++) {
             const uint32_t p = i0 + u * kS3Threads + tid;
-            if (p < npos) {
+            if (p < npos && rv[u] != 0xffffu) {
                 const uint32_t id = (uint32_t)start[hash_of(bv[u])] + rv[u];
                 rk[p] = (uint16_t)id;
                 ir[p] = id | (rv[u] << 16);
@@ -381,17 +386,17 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     //      with idx >> 15 == half is assembled in the memory of the dead count table and written out in order ----
     uint16_t *stage = reinterpret_cast<uint16_t *>(cnt);
     bool bad = false;
-    for (uint32_t half = 0; half < 2 && half * 32768u < npos; half++) {
+    for (uint32_t half = 0; half < 2 && half * 32768u < nin; half++) {
         __syncthreads(); // the table (pass C0), or the previous half's write-out, is done with this memory
         for (uint32_t i0 = 0; i0 < npos; i0 += kS3Threads * kS3Batch) {
             uint32_t iv[kS3Batch];
 #pragma unroll
             for (uint32_t u = 0; u < kS3Batch; u++) { const uint32_t p = i0 + u * kS3Threads + tid; iv[u] = p < npos ? rk[p] : ~0u; }
 #pragma unroll
-            for (uint32_t u = 0; u < kS3Batch; u++) if ((iv[u] >> 15) == half) stage[iv[u] & 32767u] = (uint16_t)(i0 + u * kS3Threads + tid);
+            for (uint32_t u = 0; u < kS3Batch; u++) if ((iv[u] >> 15) == half && iv[u] != 0xffffu) stage[iv[u] & 32767u] = (uint16_t)(i0 + u * kS3Threads + tid);
         }
         __syncthreads();
-        const uint32_t cntH = npos - half * 32768u < 32768u ? npos - half * 32768u : 32768u; // entries of this half
+        const uint32_t cntH = nin - half * 32768u < 32768u ? nin - half * 32768u : 32768u; // entries of this half
         for (uint32_t v = tid; v * 8 < cntH; v += kS3Threads) { // 8 entries = 16 bytes per lane and step
             const uint4 q = reinterpret_cast<const uint4 *>(stage)[v];
             *reinterpret_cast<uint4 *>(S + half * 32768u + v * 8) = q; // S is 16-byte aligned (kSPad); the tail past npos is don't-care
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
                 prev = cur;
             }
         }
-        if (half == 0 && npos > 32768u) { __syncthreads(); last_of_half0 = stage[32767]; } // (uniform branch)
+        if (half == 0 && nin > 32768u) { __syncthreads(); last_of_half0 = stage[32767]; } // (uniform branch)
     }
     if (bad) atomicOr(fault, 1u);
 }
@@ -764,7 +769,8 @@ __device__ inline void tile_exits(uint8_t *pl, const uint32_t *gm, const uint32_
     uint16_t *wcnt = reinterpret_cast<uint16_t *>(pl + kWords * 4);
     uint32_t *wtot = reinterpret_cast<uint32_t *>(pl + kWords * 6);
     uint16_t *N = reinterpret_cast<uint16_t *>(pl + kWords * 6 + 64);
-    static_assert(kWords * 6 + 64 + (kTileH1 / 3 + 2) * 2 <= kM3DataLds, "the successor table fits the chunk's LDS");
+    constexpr uint32_t kCapNodes = (kM3DataLds - (kWords * 6 + 64)) / 2; // game starts the table has room for
+    static_assert(kCapNodes < 0x8000u && kCapNodes > kTileH1 / 3, "a path's game starts are three positions apart at least; different paths' need not be");
     const uint32_t lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t per = kWords / T;
     uint32_t sum = 0, cnt[per];
@@ -786,6 +792,23 @@ __device__ inline void tile_exits(uint8_t *pl, const uint32_t *gm, const uint32_
     uint32_t nn = 0;
     for (uint32_t w = 0; w < T / 64; w++) nn += wtot[w]; // game starts of the tile
     auto rank_of = [&](uint32_t p) { return (uint32_t)wcnt[p >> 5] + (uint32_t)__builtin_popcount(HAS[p >> 5] & ~(~0u << (p & 31u))); };
+    if (nn > kCapNodes) { // (uniform) walkers that never met -- long runs, short periods: every entry's path is walked by a lane of its own, a global load per game
+        for (uint32_t k = tid; k < kTileExitStride; k += T) {
+            uint32_t v = 0;
+            if (k < nent) {
+                const uint32_t e = h0 + k;
+                uint32_t p = e < h1 ? next_bit(HAS, e, kWords) : kNone, x = e > h1 ? e : h1;
+                while (p != kNone && p < h1) {
+                    const uint32_t gv = __hip_atomic_load(gm + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q = p + (gv >> 24) + ((gv >> 15) & 511u);
+                    x = q > h1 ? q : h1;
+                    p = q < h1 ? next_bit(HAS, q, kWords) : kNone;
+                }
+                v = x - h1;
+            }
+            exits[k] = (uint16_t)v;
+        }
+        return;
+    }
     constexpr uint32_t kExit = 0x8000u; // N[i] = kExit | (exit - h1), or the number of the next game start on the path
     for (uint32_t p0 = h0 & ~31u; p0 < h1; p0 += T * 8) {
         uint32_t gv[8];
