@@ -158,10 +158,11 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
 /* ---- ONE continuous stream, feed by feed (zlib_amd/csrc/zgpu_cont.hip): what deflate() of the zlib API is built on ----
  * The stream's state between feeds lives with the CALLER (zgpu_cont_state + the tokens of the block that is still filling); the engine keeps nothing.
  * All positions are positions in the stream (a preset dictionary's bytes count: the first one is position 0).
- *   buf        the bytes the parse can still reach followed by the bytes it has not parsed: buf[0] is stream position cs->abs0, which must be at most
+ *   hist, in   buf = hist followed by in (two host buffers, so that a caller's large input need not be copied behind the little history the stream keeps):
+ *              the bytes the parse can still reach followed by the bytes it has not parsed.  buf[0] is stream position cs->abs0, which must be at most
  *              cs->entry - 32512 (or 0) -- and at most cs->block_start when that lies within 65536 + 512 of cs->entry (a block that may still be stored
  *              is copied from there)
- *   check_from offset into buf of the first byte this feed brings: res->adler32 / crc32 cover buf[check_from ..) alone (buf_bytes: nothing)
+ *   check_from offset into buf of the first byte whose checksum is wanted: res->adler32 / crc32 cover buf[check_from ..) alone (hist_bytes + in_bytes: nothing)
  *   mode       ZGPU_CONT_MORE: more input follows; the parse stops 512 bytes (or a little less) in front of the end of buf and cs->entry says where --
  *              the caller keeps the bytes from cs->entry - 32512 on for the next feed.  ZGPU_CONT_FLUSH: the segment ends here as at Z_SYNC_FLUSH /
  *              Z_PARTIAL_FLUSH / Z_FULL_FLUSH (lookahead runs out at the end of buf, the block that is filling is closed; the marker behind it is the
@@ -184,8 +185,8 @@ typedef struct {
     uint32_t last_eob;    /* in/out: last_eob_len (qcsrc/trees.c:1117) -- what _tr_align looks at; 8 for a fresh stream */
 } zgpu_cont_state;
 uint64_t zgpu_deflate_cont_bound(uint64_t buf_bytes); /* output capacity that is enough for one feed */
-int zgpu_deflate_cont_host(zgpu_engine *e, const void *buf, uint64_t buf_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode, zgpu_cont_state *cs,
-                           uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res);
+int zgpu_deflate_cont_host(zgpu_engine *e, const void *hist, uint64_t hist_bytes, const void *in, uint64_t in_bytes, uint64_t check_from, const zgpu_deflate_params *p,
+                           int mode, zgpu_cont_state *cs, uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res);
 
 /* Batch of independent small buffers: segment k = in[seg_offsets[k] .. seg_offsets[k+1]), each at most
  * 65536 bytes, becomes one chunk.  With ZGPU_F_FINAL every segment is a complete raw-deflate stream of its

@@ -813,10 +813,11 @@ uint64_t zgpu_deflate_cont_bound(uint64_t in_bytes)
     return in_bytes + ((in_bytes + 7) >> 3) + ((in_bytes + 63) >> 6) + 5 * (in_bytes / 16383 + 2) + 64;
 }
 
-int zgpu_deflate_cont_host(zgpu_engine *e, const void *buf, uint64_t buf_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode, zgpu_cont_state *cs,
-                           uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res)
+int zgpu_deflate_cont_host(zgpu_engine *e, const void *hist, uint64_t hist_bytes, const void *in, uint64_t in_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode,
+                           zgpu_cont_state *cs, uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res)
 {
-    if (!e || !p || !res || !cs || !carry_tok || (!buf && buf_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    if (!e || !p || !res || !cs || !carry_tok || (!hist && hist_bytes) || (!in && in_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
+    const uint64_t buf_bytes = hist_bytes + in_bytes;
     if (p->level < 1 || p->level > 9 || p->strategy < 0 || p->strategy > (int)kFixed || mode < ZGPU_CONT_MORE || mode > ZGPU_CONT_FINISH) return fail(e, ZGPU_STREAM_ERROR, "level 1..9, strategy 0..4, a ZGPU_CONT_* mode");
     if (e->geo_w != 15 || e->geo_m != 8) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: the default geometry");
     ZGPU_HIP_CHECK(hipSetDevice(e->device));
@@ -828,7 +829,8 @@ int zgpu_deflate_cont_host(zgpu_engine *e, const void *buf, uint64_t buf_bytes, 
     if (rc) return rc;
     if ((rc = ensure_cont_ws(e, 1, 1))) return rc;
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
-    if (buf_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, buf, buf_bytes, hipMemcpyHostToDevice, e->stream));
+    if (hist_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in, hist, hist_bytes, hipMemcpyHostToDevice, e->stream));
+    if (in_bytes) ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_in + hist_bytes, in, in_bytes, hipMemcpyHostToDevice, e->stream));
     if (cs->carry_ntok) ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_carry_in, carry_tok, (size_t)cs->carry_ntok * 4, hipMemcpyHostToDevice, e->stream));
     const uint32_t first_word = cs->bit_value & ((1u << cs->bit_count) - 1u);
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_out, &first_word, 4, hipMemcpyHostToDevice, e->stream));

@@ -80,7 +80,7 @@ def load_library():
     L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_cont_bound.argtypes = [u64]
     L.zgpu_deflate_cont_bound.restype = u64
-    L.zgpu_deflate_cont_host.argtypes = [vp, vp, u64, u64, C.POINTER(_Params), C.c_int, C.POINTER(ContState), vp, vp, u32, vp, u64, C.POINTER(DeflateResult)]
+    L.zgpu_deflate_cont_host.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(_Params), C.c_int, C.POINTER(ContState), vp, vp, u32, vp, u64, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_host.argtypes = [vp, vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
@@ -193,18 +193,20 @@ class Engine:
         cs = ContState(0, 0, 0, 0, 0, 0, 2, 1, 8)
         return cs, np.zeros(16384, dtype=np.uint32)
 
-    def deflate_cont_host(self, buf, check_from, level, mode, cs, carry, strategy=0, flags=0, excl=()):
+    def deflate_cont_host(self, buf, check_from, level, mode, cs, carry, strategy=0, flags=0, excl=(), split=None):
         """One feed of a continuous stream (zgpu_deflate_cont_host): buf = the history the parse can still reach + the unparsed bytes, buf[0] at stream
-        position cs.abs0.  Returns the whole bytes the feed wrote; cs and carry move on.  self.last has the checksums of buf[check_from:]."""
+        position cs.abs0 (handed over as two pieces cut at `split`, default: all of it as history-less input).  Returns the whole bytes the feed
+        wrote; cs and carry move on.  self.last has the checksums of buf[check_from:]."""
         import numpy as np
         arr = np.frombuffer(bytes(buf) + b"\0", dtype=np.uint8)
         n = int(arr.size) - 1
+        split = 0 if split is None else min(max(split, 0), n)
         cap = self.L.zgpu_deflate_cont_bound(n) + 64
         out = np.empty(cap, dtype=np.uint8)
         p = _Params(level, 0, flags, LZ_AUTO, strategy, 0)
         res = DeflateResult()
         ex = np.ascontiguousarray(list(excl) + [0], dtype=np.uint64)
-        self._check(self.L.zgpu_deflate_cont_host(self.h, arr.ctypes.data, n, check_from, C.byref(p), mode, C.byref(cs), carry.ctypes.data,
+        self._check(self.L.zgpu_deflate_cont_host(self.h, arr.ctypes.data, split, arr.ctypes.data + split, n - split, check_from, C.byref(p), mode, C.byref(cs), carry.ctypes.data,
                                                   ex.ctypes.data, len(excl), out.ctypes.data, cap, C.byref(res)))
         self.last = res
         return out[: res.out_bytes].tobytes()

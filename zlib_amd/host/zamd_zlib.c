@@ -258,6 +258,21 @@ struct internal_state {
     uint32_t dictid;  /* Adler-32 of the dictionary (header field, deflate.c:646-649, inflate.c:623-627) */
     gz_headerp gzhead; /* deflateSetHeader / inflateGetHeader */
     int tuned; uint32_t tune[4]; /* deflateTune: good_length, max_lazy, nice_length, max_chain */
+    /* deflate, ONE CONTINUOUS STREAM (the default at windowBits 15 / memLevel 8): what the reference's deflate() emits for the same calls, byte for byte --
+     * include/zamd_gpu.h zgpu_deflate_cont_host.  The stream's state between two feeds of the engine lives here. */
+    int cont;
+    bytebuf win;          /* stream bytes from position win_abs0 on: what the parse can still reach (32512 bytes in front of cs.entry, the block that may
+                             still be stored) and everything that has not been parsed yet */
+    uint64_t win_abs0;
+    zgpu_cont_state cs;
+    uint32_t *carry;      /* the tokens of the block that is filling (ZGPU_CONT_CARRY_TOKENS words) */
+    uint64_t *excl; uint32_t nexcl, excl_cap; /* stream positions that are in no hash chain: the two in front of every flush point (and of the dictionary's end) */
+    uint64_t floor_pos;   /* nothing in front of this position is history any more (Z_FULL_FLUSH: CLEAR_HASH, deflate.c:817) */
+    uint64_t fed;         /* stream position behind the last byte received (dictionary bytes count) */
+    uint64_t checked;     /* s->adler / s->crc cover the data up to here; tail_adler / tail_crc the bytes from here to fed */
+    uint32_t tail_adler, tail_crc;
+    int flush_done;       /* the flush value of the last call that went through the engine */
+    uint64_t st_str, st_blk, st_off; /* level 0: deflate_stored's strstart, block_start and the window's first position (deflate.c:1390-1439, fill_window) */
     /* inflate */
     int mode;         /* IN_* */
     size_t in_pos;    /* first byte of `in` that has not been consumed */
@@ -282,10 +297,22 @@ static uLong bound_for(uLong n)
     uLong ref = n + (n >> 12) + (n >> 14) + 11, chunks = n ? (n + CHUNK - 1) / CHUNK : 1, ours = n + 30 * chunks + 6 + 6;
     return ref > ours ? ref : ours;
 }
-EXPORT uLong compressBound(uLong sourceLen) { return bound_for(sourceLen); }
+static int chunks_mode(void) /* ZAMD_DEFLATE_CHUNKS=1: every stream is independent 64 KiB chunks (mode B of SURVEY.md 8c, rounds 1-3's behaviour) */
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ZAMD_DEFLATE_CHUNKS"); v = e && *e && *e != '0'; }
+    return v;
+}
+/* compress.c:75-79 */
+EXPORT uLong compressBound(uLong sourceLen) { return chunks_mode() ? bound_for(sourceLen) : sourceLen + (sourceLen >> 12) + (sourceLen >> 14) + 11; }
 EXPORT uLong deflateBound(z_streamp strm, uLong sourceLen)
 {
     const int ours = strm != Z_NULL && strm->state != Z_NULL && strm->state->kind == KIND_DEFLATE, gz = ours && strm->state->wrap == 2;
+    if (!ours || strm->state->cont) { /* deflate.c:489-511 */
+        const uLong destLen = sourceLen + ((sourceLen + 7) >> 3) + ((sourceLen + 63) >> 6) + 11;
+        if (!ours || strm->state->w_bits != 15) return destLen; /* (hash_bits is 15 at memLevel 8) */
+        return sourceLen + (sourceLen >> 12) + (sourceLen >> 14) + 11; /* compressBound() */
+    }
     if (ours && (strm->state->w_bits != 15 || strm->state->mem_level != 8)) /* short blocks, and blocks a small window cannot store (the arithmetic of deflate.c:513-515 per chunk) */
         return (uLong)zgpu_deflate_bound_geometry(sourceLen, CHUNK, strm->state->w_bits, strm->state->mem_level) + 18;
     return bound_for(sourceLen) + (gz ? 12 : 0); /* 18 bytes of gzip framing instead of the 6 of zlib (deflate.c:520-534) */
@@ -304,7 +331,7 @@ static struct internal_state *state_new(z_streamp strm, int kind)
 static void state_free(z_streamp strm)
 {
     struct internal_state *s = strm->state;
-    free(s->in.p); free(s->out.p); free(s->dict.p);
+    free(s->in.p); free(s->out.p); free(s->dict.p); free(s->win.p); free(s->carry); free(s->excl);
     strm->zfree(strm->opaque, s);
     strm->state = Z_NULL;
 }
@@ -338,6 +365,10 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     if (!s) return Z_MEM_ERROR;
     strm->state = s;
     s->wrap = wrap; s->level = level; s->strategy = strategy; s->w_bits = windowBits; s->mem_level = memLevel;
+    /* one continuous stream at the default geometry; another windowBits / memLevel is served in independent chunks.
+     * (levels 1-3: the continuous deflate_fast is served since round 4 as well) */
+    s->cont = !chunks_mode() && windowBits == 15 && memLevel == 8 && (level == 0 || level >= 4 || getenv("ZAMD_CONT_FAST"));
+    if (s->cont) { s->carry = (uint32_t *)malloc((size_t)ZGPU_CONT_CARRY_TOKENS * 4); if (!s->carry) { state_free(strm); return Z_MEM_ERROR; } }
     return deflateReset(strm);
 }
 EXPORT int deflateInit_(z_streamp strm, int level, const char *version, int stream_size)
@@ -353,6 +384,9 @@ EXPORT int deflateReset(z_streamp strm)
     s->tuned = 0; /* lm_init: the level's own parameters again (deflate.c:380, 1009-1012) */
     s->status = s->wrap ? ST_INIT : ST_BUSY; s->last_flush = Z_NO_FLUSH;
     s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
+    s->win.len = 0; s->win_abs0 = 0; s->nexcl = 0; s->floor_pos = 0; s->fed = 0; s->checked = 0; s->tail_adler = 1; s->tail_crc = 0;
+    s->st_str = s->st_blk = s->st_off = 0;
+    memset(&s->cs, 0, sizeof s->cs); s->cs.data_type = 2; s->cs.first_block = 1; s->cs.last_eob = 8; /* _tr_init, trees.c:382-406 */
     return Z_OK;
 }
 EXPORT int deflateEnd(z_streamp strm)
@@ -362,15 +396,27 @@ EXPORT int deflateEnd(z_streamp strm)
     state_free(strm);
     return busy ? Z_DATA_ERROR : Z_OK; /* deflate.c:886 */
 }
+static int excl_add(struct internal_state *s, uint64_t pos);
+static int cont_rewindow(struct internal_state *s, uint64_t lo, const uint8_t *in, size_t n);
+static int cont_feed(z_streamp strm, const uint8_t *in, size_t n, int mode);
+static int tail_put(struct internal_state *s, uint32_t value, int nbits);
 /* deflate.c:315-354.  Served before the first byte of input (the reference also lets a raw stream replace its window later). */
 EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
 {
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE || d == Z_NULL) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
-    if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || s->any_block || s->in.len != 0 || strm->total_in != 0) return Z_STREAM_ERROR;
+    if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || s->any_block || s->in.len != 0 || strm->total_in != 0 || (s->cont && s->fed != 0)) return Z_STREAM_ERROR;
     if (s->wrap) strm->adler = adler32(strm->adler, d, n); /* becomes the DICTID of the header */
     if (n < 3) return Z_OK;                                /* shorter than MIN_MATCH: nothing to match against */
     const uInt max_dist = (1u << s->w_bits) - 262u, keep = n > max_dist ? max_dist : n; /* MAX_DIST: the tail of the dictionary (deflate.c:337-340) */
+    if (s->cont) { /* the dictionary is the stream's first `keep` positions: window content, all of it in the hash chains but its last two bytes (deflate.c:341-351) */
+        s->win.len = 0; s->win_abs0 = 0;
+        if (!buf_put(&s->win, d + (n - keep), keep)) return Z_MEM_ERROR;
+        s->fed = s->checked = keep; s->cs.entry = s->cs.block_start = keep; s->st_str = s->st_blk = keep; s->st_off = 0; s->nexcl = 0;
+        if (!excl_add(s, keep - 2) || !excl_add(s, keep - 1)) return Z_MEM_ERROR;
+        s->dict_pending = s->wrap ? 1 : 0; /* (only the header's PRESET_DICT flag and DICTID look at it) */
+        return Z_OK;
+    }
     s->dict.len = 0;
     if (!buf_put(&s->dict, d + (n - keep), keep)) return Z_MEM_ERROR;
     s->dict_pending = 1;
@@ -386,6 +432,20 @@ EXPORT int deflateParams(z_streamp strm, int level, int strategy)
     if (level == Z_DEFAULT_COMPRESSION) level = 6;
     if (level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED) return Z_STREAM_ERROR;
     int rc = Z_OK;
+    if (s->cont) {
+        /* deflate.c:436-448: a change of the compress FUNCTION (stored / fast / slow) flushes what has been read with Z_PARTIAL_FLUSH first; other changes
+         * take effect where the loop stands -- here: where the parse of the next feed begins, after what is waiting has been parsed as far as it goes */
+        const int f_old = s->level == 0 ? 0 : s->level <= 3 ? 1 : 2, f_new = level == 0 ? 0 : level <= 3 ? 1 : 2;
+        if (f_old != f_new && strm->total_in != 0) rc = deflate(strm, Z_PARTIAL_FLUSH);
+        else if ((level != s->level || strategy != s->strategy) && s->level != 0 && s->fed - s->cs.entry > 1024 && s->status != ST_FINISH) rc = cont_feed(strm, NULL, 0, ZGPU_CONT_MORE);
+        if (f_old != f_new) {
+            if (f_new == 0) { s->st_str = s->st_blk = s->fed; s->st_off = s->fed >= 65275u ? ((s->fed - 65275u) / 32768u + 1u) * 32768u : 0; s->cs.entry = s->fed; }
+            else if (f_old == 0) { s->cs.entry = s->cs.block_start = s->fed; s->floor_pos = s->fed; if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
+        }
+        if (s->level != level) s->tuned = 0;
+        s->level = level; s->strategy = strategy;
+        return rc;
+    }
     if ((level != s->level || strategy != s->strategy) && s->in.len != 0 && s->status != ST_FINISH) {
         rc = run_chunks(strm, s->in.p, s->in.len, 0);
         s->in.len = 0;
@@ -412,6 +472,11 @@ EXPORT int deflatePrime(z_streamp strm, int bits, int value)
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     if (bits < 0 || bits > 16 || s->in.len != 0 || s->status == ST_FINISH) return Z_STREAM_ERROR;
+    if (s->cont) { /* bi_valid = bits, bi_buf = value: whole bytes of them go out with the next output, the rest waits in the unfinished byte */
+        if (s->fed != s->cs.entry) return Z_STREAM_ERROR; /* (input that is waiting would have been partly emitted in front of the bits by the reference) */
+        s->cs.bit_count = 0; s->cs.bit_value = 0;
+        return bits == 0 || tail_put(s, (uint32_t)value & ((1u << bits) - 1u), bits) ? Z_OK : Z_MEM_ERROR;
+    }
     s->dprime = bits ? ((uint32_t)bits << 16) | ((uint32_t)value & ((1u << bits) - 1u)) : 0u;
     return Z_OK;
 }
@@ -433,8 +498,12 @@ static int state_copy(z_streamp dest, z_streamp source, int kind)
     if (!ds) return Z_MEM_ERROR;
     *ds = *ss;
     dest->state = ds;
-    if (!buf_dup(&ds->in, &ss->in) || !buf_dup(&ds->out, &ss->out) || !buf_dup(&ds->dict, &ss->dict)) {
-        free(ds->in.p); free(ds->out.p); free(ds->dict.p); dest->zfree(dest->opaque, ds); dest->state = Z_NULL;
+    ds->carry = NULL; ds->excl = NULL; ds->excl_cap = 0;
+    int ok = buf_dup(&ds->in, &ss->in) && buf_dup(&ds->out, &ss->out) && buf_dup(&ds->dict, &ss->dict) && buf_dup(&ds->win, &ss->win);
+    if (ok && ss->carry) { ds->carry = (uint32_t *)malloc((size_t)ZGPU_CONT_CARRY_TOKENS * 4); ok = ds->carry != NULL; if (ok) memcpy(ds->carry, ss->carry, (size_t)ZGPU_CONT_CARRY_TOKENS * 4); }
+    if (ok && ss->nexcl) { ds->excl = (uint64_t *)malloc((size_t)ss->nexcl * sizeof(uint64_t)); ok = ds->excl != NULL; if (ok) { memcpy(ds->excl, ss->excl, (size_t)ss->nexcl * sizeof(uint64_t)); ds->excl_cap = ss->nexcl; } }
+    if (!ok) {
+        free(ds->in.p); free(ds->out.p); free(ds->dict.p); free(ds->win.p); free(ds->carry); free(ds->excl); dest->zfree(dest->opaque, ds); dest->state = Z_NULL;
         return Z_MEM_ERROR;
     }
     return Z_OK;
@@ -496,6 +565,203 @@ static int stored_chunks(bytebuf *out, const uint8_t *src, size_t n, int final, 
         if (!last) { static const uint8_t marker[5] = {0, 0, 0, 0xff, 0xff}; if (!buf_put(out, marker, 5)) return 0; }
     }
     return 1;
+}
+
+
+/* ======================================================================== deflate: ONE CONTINUOUS STREAM
+ * What the reference's deflate() emits for the same sequence of calls (deflate.c:552-856 with deflate_stored / deflate_fast / deflate_slow behind it),
+ * byte for byte, whatever the size of the input: the engine parses the stream in feeds (zgpu_deflate_cont_host, include/zamd_gpu.h), this file keeps
+ * what lies between two feeds -- the bytes the parse can still reach, the tokens of the block that is filling, the bits of the unfinished byte -- and
+ * writes what is framing: flush markers (trees.c:867-879, 892-915), stored blocks of level 0 (deflate.c:1390-1439), header and trailer.
+ * Where the reference parses while the input trickles in, this library collects: a Z_NO_FLUSH call hands its bytes to the engine once ZAMD_FEED_BYTES
+ * (default 16 MiB) of unparsed input have gathered; flushes and Z_FINISH hand over everything.  The stream's bytes do not depend on that.
+ * Not modelled: deflateParams() between two levels of the same compress function while unflushed input is waiting (the reference switches the
+ * parameters at the position its loop happens to stand at, deflate.c:436-448; here they change where the parse of the next feed begins), and a
+ * Z_NO_FLUSH slice that ends 5 .. 261 bytes behind a position 32768 k + 65274 whose first chain candidate lies exactly 32506 bytes back (the
+ * reference's window slides one loop iteration earlier there). */
+static int tail_put(struct internal_state *s, uint32_t value, int nbits) /* send_bits + bi_flush (trees.c:217-229, 1161-1173): whole bytes go out, fewer than 8 bits wait */
+{
+    uint64_t v = s->cs.bit_value | ((uint64_t)value << s->cs.bit_count);
+    int n = (int)s->cs.bit_count + nbits;
+    while (n >= 8) { const uint8_t b = (uint8_t)v; if (!buf_put(&s->out, &b, 1)) return 0; v >>= 8; n -= 8; }
+    s->cs.bit_count = (uint32_t)n; s->cs.bit_value = (uint32_t)v;
+    return 1;
+}
+static int tail_align(struct internal_state *s) /* bi_windup, trees.c:1178-1191 */
+{
+    if (s->cs.bit_count) { const uint8_t b = (uint8_t)s->cs.bit_value; if (!buf_put(&s->out, &b, 1)) return 0; }
+    s->cs.bit_count = 0; s->cs.bit_value = 0;
+    return 1;
+}
+static int cont_stored_block(struct internal_state *s, const uint8_t *src, size_t len, int last) /* _tr_stored_block, trees.c:867-879 */
+{
+    const uint8_t l[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)~len, (uint8_t)(~len >> 8)};
+    s->cs.last_eob = 8;
+    return tail_put(s, last ? 1u : 0u, 3) && tail_align(s) && buf_put(&s->out, l, 4) && buf_put(&s->out, src, len);
+}
+static int cont_marker(struct internal_state *s, int flush) /* deflate.c:808-819 */
+{
+    if (flush == Z_PARTIAL_FLUSH) { /* _tr_align, trees.c:892-915: one empty static block, two when the decoder's lookahead could fall short */
+        if (!tail_put(s, 2, 3) || !tail_put(s, 0, 7)) return 0;
+        if (1 + (int)s->cs.last_eob + 10 - (int)s->cs.bit_count < 9 && (!tail_put(s, 2, 3) || !tail_put(s, 0, 7))) return 0;
+        s->cs.last_eob = 7;
+        return 1;
+    }
+    return cont_stored_block(s, NULL, 0, 0);
+}
+static int excl_add(struct internal_state *s, uint64_t pos)
+{
+    if (s->nexcl && s->excl[s->nexcl - 1] >= pos) return 1; /* (ascending, no duplicates: flush points only move forward) */
+    if (s->nexcl == s->excl_cap) {
+        const uint32_t nc = s->excl_cap ? s->excl_cap * 2 : 64;
+        uint64_t *q = (uint64_t *)realloc(s->excl, (size_t)nc * sizeof *q);
+        if (!q) return 0;
+        s->excl = q; s->excl_cap = nc;
+    }
+    s->excl[s->nexcl++] = pos;
+    return 1;
+}
+/* the window after a feed (or an append): bytes [lo, end) of (win followed by in) */
+static int cont_rewindow(struct internal_state *s, uint64_t lo, const uint8_t *in, size_t n)
+{
+    const uint64_t old_end = s->win_abs0 + s->win.len;
+    if (lo < s->win_abs0) lo = s->win_abs0;
+    if (lo >= old_end) { /* everything that stays comes from `in` */
+        const size_t skip = (size_t)(lo - old_end);
+        s->win.len = 0; s->win_abs0 = lo;
+        return skip >= n || buf_put(&s->win, in + skip, n - skip);
+    }
+    const size_t drop = (size_t)(lo - s->win_abs0);
+    if (drop) { memmove(s->win.p, s->win.p + drop, s->win.len - drop); s->win.len -= drop; s->win_abs0 = lo; }
+    return n == 0 || buf_put(&s->win, in, n);
+}
+static void cont_checks_done(z_streamp strm) /* strm->adler covers every byte received (deflate.c:968-970 applies it slice by slice) */
+{
+    struct internal_state *s = strm->state;
+    const uint64_t tail = s->fed - s->checked;
+    if (s->wrap == 2) strm->adler = tail ? crc_join(s->crc, s->tail_crc, tail) : s->crc;
+    else if (s->wrap) strm->adler = tail ? adler_join(s->adler, s->tail_adler, tail) : s->adler;
+}
+/* one feed of the engine: the window so far + `in` (n bytes that have not been appended to the window) */
+static int cont_feed(z_streamp strm, const uint8_t *in, size_t n, int mode)
+{
+    struct internal_state *s = strm->state;
+    if (!engine_get()) { strm->msg = g_engine_err; return Z_MEM_ERROR; }
+    const uint64_t cap = zgpu_deflate_cont_bound(s->win.len + n) + 64;
+    if (!buf_reserve(&s->out, cap)) return Z_MEM_ERROR;
+    zgpu_deflate_params p = {s->level, 0, s->wrap == 2 ? ZGPU_F_CRC32 : 0u, ZGPU_LZ_AUTO, s->strategy, 0};
+    zgpu_deflate_result r;
+    s->cs.abs0 = s->win_abs0;
+    zgpu_engine *e = engine_checkout();
+    zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+    const int rc = zgpu_deflate_cont_host(e, s->win.p, s->win.len, in, n, s->checked - s->win_abs0, &p, mode, &s->cs, s->carry, s->excl, s->nexcl, s->out.p + s->out.len, cap, &r);
+    zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
+    engine_checkin(e);
+    if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
+    s->out.len += r.out_bytes;
+    const uint64_t new_fed = s->fed + n, nck = new_fed - s->checked;
+    if (nck) { s->adler = adler_join(s->adler, r.adler32, nck); if (s->wrap == 2) s->crc = crc_join(s->crc, r.crc32, nck); }
+    s->checked = new_fed; s->tail_adler = 1; s->tail_crc = 0;
+    if (s->cs.data_type != 2) strm->data_type = (int)s->cs.data_type; /* the first block has decided (trees.c:934-935) */
+    s->any_block = 1;
+    /* what the next feed can still reach: 32512 bytes in front of the parse (MAX_DIST and the engine's tiles), and the block that is filling while it may
+     * still be stored (its first byte must not have left the reference's window: at most 64 KiB + a game in front of where the parse stands) */
+    uint64_t lo = s->cs.entry > 32512 ? s->cs.entry - 32512 : 0;
+    if (lo < s->floor_pos) lo = s->floor_pos;
+    if (s->cs.entry - s->cs.block_start <= 65536 + 512 && s->cs.block_start < lo) lo = s->cs.block_start;
+    if (!cont_rewindow(s, lo, in, n)) return Z_MEM_ERROR;
+    s->fed = new_fed;
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < s->nexcl; i++) if (s->excl[i] >= s->win_abs0) s->excl[k++] = s->excl[i];
+    s->nexcl = k;
+    return Z_OK;
+}
+/* level 0: deflate_stored (deflate.c:1390-1439) over the window, with fill_window's arithmetic (deflate.c:1266-1358) -- which bytes end up in which block
+ * depends on how the input arrives, so it runs in every call.  The window holds everything from st_blk on. */
+static int cont_stored(z_streamp strm, int flush)
+{
+    struct internal_state *s = strm->state;
+    const uint64_t W = 32768, MAXD = W - 262, max_block = 65536 - 5; /* min(0xffff, pending_buf_size - 5) at memLevel 8 */
+    uint64_t filled = s->cs.entry; /* strstart + lookahead (kept in cs.entry between calls: a cut at max_block leaves lookahead behind) */
+    for (;;) {
+        if (filled - s->st_str <= 1) {
+            do { /* fill_window */
+                if (s->st_str - s->st_off >= W + MAXD) s->st_off += W;
+                const uint64_t more = 2 * W - (filled - s->st_str) - (s->st_str - s->st_off);
+                if (filled == s->fed) break;
+                filled += s->fed - filled < more ? s->fed - filled : more;
+            } while (filled - s->st_str < 262 && filled != s->fed);
+            if (filled == s->st_str && flush == Z_NO_FLUSH) break;
+            if (filled == s->st_str) goto closing;
+        }
+        s->st_str = filled;
+        const uint64_t max_start = s->st_blk + max_block;
+        if (s->st_str >= max_start) {
+            s->st_str = max_start;
+            if (!cont_stored_block(s, s->win.p + (s->st_blk - s->win_abs0), (size_t)(s->st_str - s->st_blk), 0)) return Z_MEM_ERROR;
+            s->st_blk = s->st_str;
+        }
+        if (s->st_str - s->st_blk >= MAXD) {
+            if (!cont_stored_block(s, s->win.p + (s->st_blk - s->win_abs0), (size_t)(s->st_str - s->st_blk), 0)) return Z_MEM_ERROR;
+            s->st_blk = s->st_str;
+        }
+    }
+    s->cs.entry = filled;
+    return Z_OK;
+closing:
+    if (!cont_stored_block(s, s->win.p + (s->st_blk - s->win_abs0), (size_t)(s->st_str - s->st_blk), flush == Z_FINISH)) return Z_MEM_ERROR;
+    s->st_blk = s->st_str; s->cs.entry = filled;
+    return Z_OK;
+}
+/* the body of deflate() for a continuous stream: the caller's input is taken (read_buf, deflate.c:956-981), whatever the call makes final is appended to s->out */
+static int cont_deflate(z_streamp strm, int flush)
+{
+    struct internal_state *s = strm->state;
+    const uint8_t *src = strm->next_in; const size_t n = strm->avail_in;
+    strm->next_in += n; strm->total_in += n; strm->avail_in = 0;
+    static long feed_min = -1;
+    if (feed_min < 0) { const char *v = getenv("ZAMD_FEED_BYTES"); feed_min = v ? strtol(v, NULL, 10) : (16l << 20); if (feed_min < 1024) feed_min = 1024; }
+    if (s->level == 0) {
+        if (n) {
+            if (!buf_put(&s->win, src, n)) return Z_MEM_ERROR;
+            if (s->wrap == 2) s->crc = (uint32_t)crc32(s->crc, src, (uInt)n); else s->adler = (uint32_t)adler32(s->adler, src, (uInt)n);
+            s->fed += n; s->checked = s->fed;
+        }
+        int rc = cont_stored(strm, flush);
+        if (rc != Z_OK) return rc;
+        s->any_block = 1;
+        if (flush != Z_NO_FLUSH && flush != Z_FINISH && !cont_marker(s, flush)) return Z_MEM_ERROR;
+        if (flush == Z_FINISH && !tail_align(s)) return Z_MEM_ERROR;
+        if (flush == Z_FULL_FLUSH) s->floor_pos = s->fed;
+        if (!cont_rewindow(s, s->st_blk, NULL, 0)) return Z_MEM_ERROR; /* (the block that is filling is all that is needed) */
+        s->cs.block_start = s->st_blk;
+        cont_checks_done(strm);
+        return Z_OK;
+    }
+    const uint64_t unparsed = s->fed + n - s->cs.entry;
+    if (flush == Z_NO_FLUSH) {
+        if (unparsed < (uint64_t)feed_min) { /* collect */
+            if (n) {
+                if (!buf_put(&s->win, src, n)) return Z_MEM_ERROR;
+                if (s->wrap == 2) s->tail_crc = (uint32_t)crc32(s->tail_crc, src, (uInt)n); else s->tail_adler = (uint32_t)adler32(s->tail_adler, src, (uInt)n);
+                s->fed += n;
+            }
+            cont_checks_done(strm);
+            return Z_OK;
+        }
+        const int rc = cont_feed(strm, src, n, ZGPU_CONT_MORE);
+        cont_checks_done(strm);
+        return rc;
+    }
+    int rc = cont_feed(strm, src, n, flush == Z_FINISH ? ZGPU_CONT_FINISH : ZGPU_CONT_FLUSH);
+    if (rc != Z_OK) return rc;
+    if (flush != Z_FINISH) {
+        if (!cont_marker(s, flush)) return Z_MEM_ERROR;
+        if (flush == Z_FULL_FLUSH) { s->floor_pos = s->fed; s->nexcl = 0; if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
+        else if ((s->fed >= 2 && !excl_add(s, s->fed - 2)) || (s->fed >= 1 && !excl_add(s, s->fed - 1))) return Z_MEM_ERROR; /* never inserted: lookahead < MIN_MATCH there (deflate.c:1576) */
+    }
+    cont_checks_done(strm);
+    return Z_OK;
 }
 
 /* compress `n` bytes (whole chunks, or everything when a flush / finish asks for it) and append the result to s->out */
@@ -645,6 +911,7 @@ EXPORT int deflate(z_streamp strm, int flush)
         uint8_t h[6] = {(uint8_t)(hdr >> 8), (uint8_t)hdr, (uint8_t)(strm->adler >> 24), (uint8_t)(strm->adler >> 16), (uint8_t)(strm->adler >> 8), (uint8_t)strm->adler};
         if (!buf_put(&s->out, h, s->dict_pending ? 6 : 2)) return Z_MEM_ERROR;
         strm->adler = 1; /* deflate.c:650 */
+        if (s->cont) s->dict_pending = 0;
         s->status = ST_BUSY;
     }
     if (s->out.len - s->out_pos != 0) { /* deflate.c:757-768 */
@@ -655,7 +922,16 @@ EXPORT int deflate(z_streamp strm, int flush)
     }
     if (s->status == ST_FINISH && strm->avail_in != 0) { strm->msg = ERR_MSG(Z_BUF_ERROR); return Z_BUF_ERROR; }
 
-    if (strm->avail_in != 0 || s->in.len != 0 || (flush != Z_NO_FLUSH && s->status != ST_FINISH)) {
+    /* (a call that only comes back for the rest of a flush's output -- the call before ran out of avail_out -- does not flush again.  The reference
+     * writes one more empty block and marker in that case, deflate.c:795-806: its bytes depend on the caller's output space, these do not.) */
+    if (s->cont && (strm->avail_in != 0 || (flush != Z_NO_FLUSH && s->status != ST_FINISH && !(old_flush == -1 && s->flush_done == flush)))) {
+        const int rc = cont_deflate(strm, flush);
+        if (rc != Z_OK) return rc;
+        s->flush_done = flush;
+        if (flush == Z_FINISH) s->status = ST_FINISH;
+        deliver(strm);
+        if (strm->avail_out == 0 && (s->out.len - s->out_pos != 0 || flush != Z_FINISH)) { s->last_flush = -1; return Z_OK; }
+    } else if (!s->cont && (strm->avail_in != 0 || s->in.len != 0 || (flush != Z_NO_FLUSH && s->status != ST_FINISH))) {
         /* take the caller's input (read_buf, deflate.c:956-981) */
         const uint8_t *src = strm->next_in; size_t n = strm->avail_in;
         strm->next_in += n; strm->total_in += n; strm->avail_in = 0;
