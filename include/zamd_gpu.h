@@ -167,7 +167,11 @@ int zgpu_deflate_host(zgpu_engine *e, const void *in, uint64_t in_bytes, const z
  *              the caller keeps the bytes from cs->entry - 32512 on for the next feed.  ZGPU_CONT_FLUSH: the segment ends here as at Z_SYNC_FLUSH /
  *              Z_PARTIAL_FLUSH / Z_FULL_FLUSH (lookahead runs out at the end of buf, the block that is filling is closed; the marker behind it is the
  *              caller's to write -- it knows cs->bit_count / bit_value and cs->last_eob).  ZGPU_CONT_FINISH: the same with the final bit, padded to a byte.
- *   excl       stream positions inside buf's history that are NOT in the hash chains: the two in front of every earlier flush point (zlib 1.2.3 never
+ *   hist_bits  levels 1-3 (deflate_fast leaves the strings inside a long match out of its hash chains, qcsrc/deflate.c:1510-1534, so WHICH positions of the
+ *              history are in the chains is part of the stream's state): ZGPU_CONT_HIST_WORDS words, bit j = the position max(cs->entry - 32512, the
+ *              stream position of buf's first byte if that is later) + j is in the chains; in and out; all zero for a fresh stream, ones for a preset
+ *              dictionary's positions but its last two.  Levels 4-9 do not look at it (may be NULL).
+ *   excl       (levels 4-9) stream positions inside buf's history that are NOT in the hash chains: the two in front of every earlier flush point (zlib 1.2.3 never
  *              inserts them, qcsrc/deflate.c:1576 with lookahead < MIN_MATCH)
  *   out        whole bytes of the stream from the byte the last feed left unfinished (cs->bit_count bits of it are in cs->bit_value); res->out_bytes */
 #define ZGPU_CONT_MORE 0
@@ -185,8 +189,10 @@ typedef struct {
     uint32_t last_eob;    /* in/out: last_eob_len (qcsrc/trees.c:1117) -- what _tr_align looks at; 8 for a fresh stream */
 } zgpu_cont_state;
 uint64_t zgpu_deflate_cont_bound(uint64_t buf_bytes); /* output capacity that is enough for one feed */
+#define ZGPU_CONT_HIST_WORDS 1032
 int zgpu_deflate_cont_host(zgpu_engine *e, const void *hist, uint64_t hist_bytes, const void *in, uint64_t in_bytes, uint64_t check_from, const zgpu_deflate_params *p,
-                           int mode, zgpu_cont_state *cs, uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res);
+                           int mode, zgpu_cont_state *cs, uint32_t *carry_tok, uint32_t *hist_bits, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap,
+                           zgpu_deflate_result *res);
 
 /* Batch of independent small buffers: segment k = in[seg_offsets[k] .. seg_offsets[k+1]), each at most
  * 65536 bytes, becomes one chunk.  With ZGPU_F_FINAL every segment is a complete raw-deflate stream of its

@@ -55,7 +55,7 @@ def stream(eng, data, level, calls, strategy=0, more_at=1 << 62):
                 t.put(out, 0, 3); t.align(out); out += b"\x00\x00\xff\xff"; cs.last_eob = 8
             cs.bit_count = t.n; cs.bit_value = t.v
             if flush == 3:
-                floor = fed; excl = []
+                floor = fed; excl = []; carry[1][:] = 0
             else:
                 excl += [p for p in (fed - 2, fed - 1) if p >= floor and p >= 0 and p not in excl]
         excl = [p for p in excl if p + 40000 > cs.entry]
@@ -64,6 +64,9 @@ def stream(eng, data, level, calls, strategy=0, more_at=1 << 62):
 
 def corpus(kind, seed, nbytes):
     return CP.chunks(kind, seed, (nbytes + 65535) // 65536).tobytes()[:nbytes]
+
+
+LEVELS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "6,9,4").split(",")]
 
 
 def main():
@@ -82,7 +85,7 @@ def main():
             calls.append((pos, rnd.choice([0, 0, 0, 1, 2, 3])))
         tests.append((tuple(calls), rnd.choice([70000, 200000, 1 << 62])))
     for calls, more_at in tests:
-        for level in (6, 9, 4):
+        for level in LEVELS:
             want = R.deflate_calls(d, level, calls)
             t = time.time()
             try:

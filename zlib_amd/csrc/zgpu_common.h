@@ -129,6 +129,18 @@ __device__ inline void tile_span(const ChunkGeom &g, const TileGeom &tg, uint32_
     nent = ti == 0 ? 1u : kTileEntries;
 }
 
+// levels 1-3 of a continuous stream (fastwin_tile_kernel, zgpu_lz_fastwin.hip): what the rounds of a batch of tiles work on
+constexpr uint32_t kInsWords = (kChunkMax - kTileStride) / 32; // 1032 words: one bit per local position 32512 .. 65535, "in the hash chains"
+struct FastTiles {
+    const uint16_t *exit_cur; uint16_t *exit_new;  // [tile of the batch]: where the tile's parse ends, relative to its h1
+    const uint32_t *ins0, *ins1; uint32_t *ins0w, *ins1w; // [tile][kInsWords], two buffers
+    const uint8_t *cur;                            // [tile]: the buffer its current bits are in; a tile that is parsed writes the other one
+    const uint8_t *active; uint8_t *changed;       // [tile]
+    const uint32_t *prev_ins;                      // the bits in front of the batch's first tile (its local positions 0 .. 33023): the feed's history, or the batch before
+    uint32_t round;
+    uint32_t *dbg;                                 // (ZGPU_FAST_TRACE: eight words per tile about what changed)
+};
+
 // One block of a continuous stream (blocks are cut every 16383 tokens counted from the start of the STREAM, h/deflate.h:313): filled in by cont_table_kernel,
 // coded by huffman_kernel<true> into a slot of its own from bit 0, put in its place in the stream (a bit position) by cont_stitch_kernel.
 struct ContBlk {

@@ -125,14 +125,15 @@ __host__ __device__ inline uint64_t cont_special(uint64_t n)
 
 // the batch's blocks.  seg_end: the stream position the segment ends at when this batch reaches it (the block that is filling is closed there), ~0: more follows
 __global__ void __launch_bounds__(256) cont_table_kernel(ContBlk *__restrict__ blk, ContState *st, const uint32_t *__restrict__ T, uint64_t seg_end, uint32_t final_block,
-                                                         uint64_t sp, uint32_t nblk_cap)
+                                                         uint64_t sp, uint32_t nblk_cap, uint32_t slow)
 {
     const uint32_t total = st->total;
     uint32_t nblk = total / kBlockTokens;
     if (seg_end != ~0ull) {
         // deflate_slow tallies the last byte's pending literal BEHIND its loop without looking at "buffer full" (deflate.c:1660-1665): when that literal fills the
         // block, the full block is the segment's last; any other token that fills a block is followed by one more (possibly empty) block at the flush
-        const bool full_last = total != 0 && total % kBlockTokens == 0 && (T[total - 1] >> 8) == 0;
+        // (deflate_fast has no such literal: its last token is tallied inside the loop, deflate.c:1524-1541)
+        const bool full_last = slow && total != 0 && total % kBlockTokens == 0 && (T[total - 1] >> 8) == 0;
         if (!full_last) nblk++;
     }
     if (nblk > nblk_cap) nblk = nblk_cap; // (cannot happen: the capacity is computed from the positions of the batch)
@@ -148,7 +149,10 @@ __global__ void __launch_bounds__(256) cont_table_kernel(ContBlk *__restrict__ b
     k.start_pos = b == 0 ? st->block_start : blk[b - 1].end_pos;
     k.eof = final_block && b + 1 == nblk;
     k.first = st->first_block && b == 0;
-    const uint64_t ptop = k.end_pos - k.last_len + 1;
+    // where the loop stood when the block was flushed: deflate_slow emits a token one iteration late (the match of position m while it stands at m + 1,
+    // deflate.c:1617-1640; a literal likewise, :1644-1656), deflate_fast in the iteration of the token's own position (:1499-1541); at a segment's end both
+    // flush behind the loop, which stands at the end then (last_len is 1 there and end_pos the end: the slow formula)
+    const uint64_t ptop = k.end_pos - k.last_len + ((slow || !complete) ? 1 : 0);
     k.nostore = k.start_pos < 32768u * cont_slides(ptop, sp);
     k.nbits = 0; k.btype = 0; k.stored_len = 0; k.eob_len = 8;
 }
@@ -271,11 +275,11 @@ void launch_chain(const uint16_t *exits, uint32_t ntiles, uint16_t *comp, uint16
 uint32_t chain_groups(uint32_t ntiles) { return (ntiles + kChainGroup - 1) / kChainGroup; }
 
 void launch_cont_tokens(const ChunkGeom &g, const TileGeom &tg, const uint32_t *tokens, const ChunkMeta *tmeta, ContState *st, uint32_t *tokoff, const uint32_t *carry, uint32_t *T,
-                        ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, hipStream_t s)
+                        ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, bool slow, hipStream_t s)
 {
     hipLaunchKernelGGL(cont_tokscan_kernel, dim3(1), dim3(1024), 0, s, tmeta, g.nchunks, st, tokoff, carry, T);
     if (g.nchunks) hipLaunchKernelGGL(cont_compact_kernel, dim3(g.nchunks), dim3(256), 0, s, g, tg, tokens, tmeta, tokoff, T, blk);
-    hipLaunchKernelGGL(cont_table_kernel, dim3((nblk_cap + 255) / 256), dim3(256), 0, s, blk, st, T, seg_end, final_block ? 1u : 0u, sp, nblk_cap);
+    hipLaunchKernelGGL(cont_table_kernel, dim3((nblk_cap + 255) / 256), dim3(256), 0, s, blk, st, T, seg_end, final_block ? 1u : 0u, sp, nblk_cap, slow ? 1u : 0u);
 }
 void launch_cont_stitch(const ContBlk *blk, ContState *st, uint64_t *pos, const uint8_t *slots, uint32_t slot_stride, const uint8_t *in, uint64_t abs0, uint8_t *out, uint64_t out_cap,
                         uint32_t nblk_cap, const uint32_t *T, uint32_t *carry, uint64_t seg_end, hipStream_t s)

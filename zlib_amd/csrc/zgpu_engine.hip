@@ -34,8 +34,16 @@ uint32_t *lz_sorted_fault_word(void *workspace);
 void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, uint16_t *comp, uint16_t *gentry, hipStream_t st,
                      void *prof, int exact_sort);
 uint32_t chain_groups(uint32_t ntiles);
+void launch_sort_tiles(const ChunkGeom &g, void *workspace, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, const uint16_t **S_out, const uint32_t **ir_out);
+void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st);
+void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
+                      uint32_t *count, hipStream_t st);
+void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
+                        hipStream_t st);
+void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st);
 void launch_cont_tokens(const ChunkGeom &g, const TileGeom &tg, const uint32_t *tokens, const ChunkMeta *tmeta, ContState *st, uint32_t *tokoff, const uint32_t *carry, uint32_t *T,
-                        ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, hipStream_t s);
+                        ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, bool slow, hipStream_t s);
 void launch_huffman_cont(const ChunkGeom &g, const uint32_t *compact_tokens, uint32_t nblk, ContBlk *blk, ContState *cst, uint8_t *slots, hipStream_t st, bool fixed_trees);
 void launch_cont_stitch(const ContBlk *blk, ContState *st, uint64_t *pos, const uint8_t *slots, uint32_t slot_stride, const uint8_t *in, uint64_t abs0, uint8_t *out, uint64_t out_cap,
                         uint32_t nblk_cap, const uint32_t *T, uint32_t *carry, uint64_t seg_end, hipStream_t s);
@@ -93,6 +101,11 @@ struct zgpu_engine {
     zgpu::ContBlk *ct_blk = nullptr; uint64_t *ct_pos = nullptr; uint8_t *ct_slots = nullptr; zgpu::ContState *ct_st = nullptr;
     zgpu::ChunkMeta *ct_ckmeta = nullptr; uint64_t ct_ck_cap = 0;
     uint64_t *ct_excl = nullptr; uint32_t ct_excl_cap = 0;
+    // ... levels 1-3: the rounds of fastwin_tile_kernel
+    uint32_t cf_tiles = 0;
+    uint16_t *cf_exit_a = nullptr, *cf_exit_b = nullptr; uint32_t *cf_ins0 = nullptr, *cf_ins1 = nullptr, *cf_prev = nullptr, *cf_prev2 = nullptr, *cf_hist = nullptr, *cf_count = nullptr;
+    uint8_t *cf_cur = nullptr, *cf_act_a = nullptr, *cf_act_b = nullptr, *cf_changed = nullptr;
+    uint64_t cf_rounds = 0, cf_tile_parses = 0; // (diagnostic: rounds and tile parses since the engine was made)
     // profiling
     bool prof = false;
     double ms[ZGPU_STAGE_COUNT] = {0};
@@ -524,6 +537,72 @@ static int ensure_cont_ws(zgpu_engine *e, uint32_t batch_tiles, uint64_t feed_ti
     return ZGPU_OK;
 }
 
+static int ensure_fast_ws(zgpu_engine *e, uint32_t batch_tiles)
+{
+    int rc;
+    if (!e->cf_prev) {
+        if ((rc = dev_alloc(e, &e->cf_prev, kInsWords + 8))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_prev2, kInsWords + 8))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_hist, kInsWords + 8))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_count, 4))) return rc;
+    }
+    if (batch_tiles > e->cf_tiles) {
+        hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed);
+        e->cf_exit_a = e->cf_exit_b = nullptr; e->cf_ins0 = e->cf_ins1 = nullptr; e->cf_cur = e->cf_act_a = e->cf_act_b = e->cf_changed = nullptr; e->cf_tiles = 0;
+        if ((rc = dev_alloc(e, &e->cf_exit_a, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_exit_b, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_ins0, (size_t)batch_tiles * kInsWords))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_ins1, (size_t)batch_tiles * kInsWords))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_cur, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_act_a, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_act_b, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_changed, (size_t)batch_tiles))) return rc;
+        e->cf_tiles = batch_tiles;
+    }
+    return ZGPU_OK;
+}
+// levels 1-3: the tiles of one batch by rounds (zgpu_lz_fastwin.hip, fastwin_tile_kernel): until no tile's predecessor has changed
+static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg, const LevelCfg &cfg, hipStream_t st)
+{
+    const uint32_t nb = g.nchunks;
+    const uint16_t *S; const uint32_t *ir;
+    launch_sort_tiles(g, e->par_ws, e->meta, st, e, e->exact_sort, &S, &ir);
+    StageTimer t(e, st, ZGPU_STAGE_MATCH);
+    launch_fast_init(e->cf_cur, e->cf_act_a, e->cf_exit_a, nb, st);
+    uint8_t *act = e->cf_act_a, *act_next = e->cf_act_b;
+    for (uint32_t round = 0;; round++) {
+        FastTiles ft{};
+        ft.exit_cur = e->cf_exit_a; ft.exit_new = e->cf_exit_b; ft.ins0 = ft.ins0w = e->cf_ins0; ft.ins1 = ft.ins1w = e->cf_ins1; ft.cur = e->cf_cur; ft.active = act; ft.changed = e->cf_changed;
+        ft.prev_ins = e->cf_prev; ft.round = round;
+        static uint32_t *dbg = nullptr;
+        const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
+        if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
+        ft.dbg = trace && nb <= 65536 ? dbg : nullptr;
+        if (ft.dbg) hipMemsetAsync(dbg, 0xff, (size_t)nb * 32, st);
+        launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, st);
+        if (ft.dbg) {
+            std::vector<uint32_t> h((size_t)nb * 8);
+            hipMemcpyAsync(h.data(), dbg, (size_t)nb * 32, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
+            for (uint32_t c = 0; c < nb && c < 40; c++) if (h[c * 8] != 0xffffffffu)
+                fprintf(stderr, "   tile %u: %u words differ (%u .. %u), exit %u (was %u), entry %u, %u tokens\n", c, h[c * 8 + 1], h[c * 8 + 2], h[c * 8 + 3], h[c * 8 + 4], h[c * 8 + 5], h[c * 8 + 6], h[c * 8 + 7]);
+        }
+        launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, st);
+        uint32_t active = 0;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(&active, e->cf_count, 4, hipMemcpyDeviceToHost, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        e->cf_rounds++; e->cf_tile_parses += round == 0 ? nb : 0;
+        static int force = -1; // ZGPU_FAST_FORCE_ROUNDS=n (debug): every tile is parsed again in each of the first n rounds
+        if (force < 0) { const char *v = getenv("ZGPU_FAST_FORCE_ROUNDS"); force = v ? atoi(v) : 0; }
+        if ((int)round < force) { ZGPU_HIP_CHECK(hipMemsetAsync(act_next + 1, 1, nb - 1, st)); active = nb - 1; }
+        if (getenv("ZGPU_FAST_TRACE")) fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again\n", round, active, nb);
+        if (active == 0) break;
+        e->cf_tile_parses += active;
+        uint8_t *x = act; act = act_next; act_next = x;
+    }
+    launch_fast_finish(e->cf_cur, e->cf_exit_a, e->cf_ins0, e->cf_ins1, nb, tg.entry + g.chunk0 + nb, e->cf_prev, e->cf_prev2, st);
+    return ZGPU_OK;
+}
+
 struct ContFeed { // one call of deflate_cont
     const uint8_t *d_buf; uint64_t buf_bytes; // history + unparsed bytes
     uint64_t check_from;                      // Adler-32 / CRC-32 of d_buf[check_from ..): the bytes this feed brought (buf_bytes: none)
@@ -531,10 +610,12 @@ struct ContFeed { // one call of deflate_cont
     const uint64_t *h_excl; uint32_t nexcl;   // stream positions that are not in the hash chains (in front of earlier flushes), ascending
     uint8_t *d_out; uint64_t out_cap; uint64_t prefix_bits;
     bool want_crc;
+    uint32_t *h_hist; // levels 1-3: "in the hash chains", one bit per position of the history (bit j: the position 32512, or all there are, in front of cs->entry, + j); in and out; kInsWords words
 };
 static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, zgpu_cont_state *cs, const uint32_t *d_carry_in, zgpu_deflate_result *res, hipStream_t st)
 {
-    if (!cfg.slow) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: levels 4..9");
+    if (!cfg.slow && (!lz_fastwin_serves(cfg) || cfg.strategy == kHuffmanOnly || cfg.strategy == kRle || !f.h_hist))
+        return fail(e, ZGPU_STREAM_ERROR, "continuous stream at levels 1..3: the levels' own parameters, not Z_HUFFMAN_ONLY / Z_RLE");
     if (cs->entry < cs->abs0 || cs->entry > cs->abs0 + f.buf_bytes || cs->carry_ntok >= kBlockTokens || cs->bit_count > 7) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: state out of range");
     if ((reinterpret_cast<uintptr_t>(f.d_out) & 3) != 0) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: the output must be 4-byte aligned");
     const uint64_t e0 = cs->entry - cs->abs0, w0 = e0 > kTileStride ? e0 - kTileStride : 0;
@@ -557,6 +638,10 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     int rc = ensure_deflate_ws(e, batch, false, 1);
     if (rc) return rc;
     if ((rc = ensure_cont_ws(e, batch, ntiles))) return rc;
+    if (!cfg.slow) {
+        if ((rc = ensure_fast_ws(e, batch))) return rc;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(e->cf_prev, f.h_hist, (size_t)kInsWords * 4, hipMemcpyHostToDevice, st)); // (pageable: the copy has read it when the call returns)
+    }
     const uint64_t seg_end = ends ? cs->abs0 + f.buf_bytes : ~0ull, sp = ends ? cont_special_pos(seg_end) : ~0ull;
     uint32_t nexcl_dev = 0;
     if (f.nexcl) {
@@ -588,11 +673,12 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
         const uint32_t nb = (uint32_t)(ntiles - t0 < batch ? ntiles - t0 : batch);
         const bool last_batch = t0 + nb >= ntiles;
         g.chunk0 = t0; g.nchunks = nb;
-        if (nb) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
+        if (nb && cfg.slow) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
+        else if (nb && (rc = lz_tiles_fast(e, g, tg, cfg, st))) return rc;
         const uint64_t seg_here = (ends && last_batch) ? seg_end : ~0ull;
         {
             StageTimer t(e, st, ZGPU_STAGE_PARSE);
-            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH && seg_here != ~0ull, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, st);
+            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH && seg_here != ~0ull, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, cfg.slow != 0, st);
         }
         {
             StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
@@ -641,6 +727,16 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     if (ntiles) {
         const uint64_t wb_last = w0 + (ntiles - 1) * kTileStride, lim = end - wb_last, h1_last = lim < kTileH1 ? lim : kTileH1;
         cs->entry = cs->abs0 + wb_last + h1_last + k_next;
+    }
+    if (!cfg.slow) { // the history's bits for the next feed: the 32512 positions (or all there are) in front of where the parse stands
+        uint32_t x0 = 0, count = 0;
+        if (ntiles) {
+            const uint64_t wb_last = w0 + (ntiles - 1) * kTileStride, e_buf = cs->entry - cs->abs0, nw0 = e_buf > kTileStride && e_buf - kTileStride > w0 ? e_buf - kTileStride : w0;
+            x0 = (uint32_t)(nw0 - wb_last); count = (uint32_t)(e_buf - nw0);
+            launch_fast_hist(e->cf_prev2, e->cf_prev, x0, count, e->cf_hist, st);
+            ZGPU_HIP_CHECK(hipMemcpyAsync(f.h_hist, e->cf_hist, (size_t)kInsWords * 4, hipMemcpyDeviceToHost, st));
+            ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        }
     }
     if (ends) cs->entry = seg_end;
     cs->block_start = hs.block_start; cs->carry_ntok = hs.carry_n; cs->data_type = hs.data_type; cs->first_block = hs.first_block; cs->last_eob = hs.last_eob;
@@ -715,6 +811,8 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipFree(e->hand_list); hipFree(e->tokens); hipFree(e->meta); hipFree(e->slots); hipFree(e->tables); hipFree(e->geo_slots); hipFree(e->geo_tables); hipFree(e->geo_nostore); hipFree(e->par_ws); hipFree(e->offsets); hipFree(e->run);
     hipFree(e->ct_exits); hipFree(e->ct_entry); hipFree(e->ct_comp); hipFree(e->ct_gentry); hipFree(e->ct_tokoff); hipFree(e->ct_T); hipFree(e->ct_carry); hipFree(e->ct_carry_in); hipFree(e->ct_blk);
     hipFree(e->ct_pos); hipFree(e->ct_slots); hipFree(e->ct_st); hipFree(e->ct_ckmeta); hipFree(e->ct_excl);
+    hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_prev); hipFree(e->cf_prev2); hipFree(e->cf_hist); hipFree(e->cf_count);
+    hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
@@ -784,6 +882,8 @@ static int deflate_cont_oneshot(zgpu_engine *e, const uint8_t *d_in, uint64_t in
     zgpu_cont_state cs{}; cs.data_type = 2; cs.first_block = 1; cs.last_eob = 8;
     ContFeed f{}; f.d_buf = d_in; f.buf_bytes = in_bytes; f.check_from = 0; f.mode = ZGPU_CONT_FINISH; f.d_out = d_out; f.out_cap = out_cap - tail_bytes; f.prefix_bits = 8ull * head_bytes;
     f.want_crc = gz || (p->flags & ZGPU_F_CRC32);
+    std::vector<uint32_t> hist(kInsWords + 8, 0u); // (a fresh stream: nothing is in the chains)
+    f.h_hist = hist.data();
     int rc = ensure_cont_ws(e, 1, 1);
     if (rc) return rc;
     rc = deflate_cont(e, f, cfg, &cs, e->ct_carry_in, res, st);
@@ -814,7 +914,7 @@ uint64_t zgpu_deflate_cont_bound(uint64_t in_bytes)
 }
 
 int zgpu_deflate_cont_host(zgpu_engine *e, const void *hist, uint64_t hist_bytes, const void *in, uint64_t in_bytes, uint64_t check_from, const zgpu_deflate_params *p, int mode,
-                           zgpu_cont_state *cs, uint32_t *carry_tok, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res)
+                           zgpu_cont_state *cs, uint32_t *carry_tok, uint32_t *hist_bits, const uint64_t *excl, uint32_t nexcl, void *out, uint64_t out_cap, zgpu_deflate_result *res)
 {
     if (!e || !p || !res || !cs || !carry_tok || (!hist && hist_bytes) || (!in && in_bytes) || !out) return fail(e, ZGPU_STREAM_ERROR, "null argument");
     const uint64_t buf_bytes = hist_bytes + in_bytes;
@@ -836,7 +936,7 @@ int zgpu_deflate_cont_host(zgpu_engine *e, const void *hist, uint64_t hist_bytes
     ZGPU_HIP_CHECK(hipMemcpyAsync(e->stage_out, &first_word, 4, hipMemcpyHostToDevice, e->stream));
     ZGPU_HIP_CHECK(hipStreamSynchronize(e->stream));
     ContFeed f{}; f.d_buf = e->stage_in; f.buf_bytes = buf_bytes; f.check_from = check_from; f.mode = mode; f.h_excl = excl; f.nexcl = nexcl;
-    f.d_out = e->stage_out; f.out_cap = bound; f.prefix_bits = cs->bit_count; f.want_crc = (p->flags & ZGPU_F_CRC32) != 0;
+    f.d_out = e->stage_out; f.out_cap = bound; f.prefix_bits = cs->bit_count; f.want_crc = (p->flags & ZGPU_F_CRC32) != 0; f.h_hist = hist_bits;
     rc = deflate_cont(e, f, cfg, cs, e->ct_carry_in, res, e->stream);
     if (rc) return rc;
     if (res->out_bytes > out_cap) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");

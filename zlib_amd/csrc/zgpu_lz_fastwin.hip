@@ -389,6 +389,321 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     if (lane == 0) { meta[cm].ntok = ntok; meta[cm].nostore = nostore; meta[cm].in_bytes = n; }
 }
 
+// ======================================================================================================================================
+// The same parse for a TILE of a continuous stream (zgpu_cont.hip; round 4).  deflate_fast's state at a token start is the position AND which of the
+// 32506 positions in front of it are in the hash chains -- the strings inside a long match are not -- so a tile cannot be parsed before the tile in
+// front of it has been.  It can be GUESSED, though: in round 0 every tile but the batch's first parses its own history as well, from nothing (a warm-up:
+// 32512 positions later the parse and the chains have almost always fallen into step with the stream's); from round 1 on a tile whose predecessor's
+// results have changed is parsed again from where the predecessor's parse ended, with the predecessor's "inserted" bits as its history; a round in which
+// no tile's results (exit, bits) change has reached the one consistent assignment, which is the reference's parse (the recursion tile i = F(tile i - 1)
+// has exactly one solution).  The engine runs rounds until no tile is active (zgpu_engine.hip, deflate_cont).
+//   ins (per tile, two buffers): one bit per local position 32512 .. 65535: "in the chains", valid below the tile's exit -- read by the tile behind it,
+//   for which these are its local positions 0 .. 33023.
+// Block cuts, the window's slides and the stored-block veto are the stream's business (cont_table_kernel), not the tile's.
+template <int CHAIN, int NICE>
+__global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom tg, FastTiles ft, uint32_t max_insert, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
+                                                           uint32_t *__restrict__ tokens, ChunkMeta *__restrict__ meta)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
+    constexpr int NW = NICE / 8;
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (ft.round != 0 && !ft.active[c]) return;
+    const bool warm = ft.round == 0 && c != 0;
+    uint64_t wb; uint32_t n, h0, h1, nent;
+    tile_span(g, tg, c, wb, n, h0, h1, nent);
+    const uint8_t *src = g.in + wb;
+    const uint64_t safe_end = g.in_bytes - wb;
+    const uint16_t *S = S_all + (size_t)c * kSStrideF + kSPadF;
+    const uint32_t *ir = ir_all + (size_t)c * kChunkMax;
+    uint32_t *tok = tokens + (size_t)c * kChunkMax;
+    const uint32_t base = (tg.abs0_nil && tg.abs0 + wb == 0) ? 0u : 1u, npos = n >= 3 ? n - 2 : 0;
+    const uint32_t nil_local = (tg.nil_pos >= wb && tg.nil_pos - wb < kChunkMax) ? (uint32_t)(tg.nil_pos - wb) : ~0u;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
+    const uint32_t ring_a = fw_lds_base(fw_lds);
+    const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
+    const uint32_t entry_pos = warm ? 0u : (c == 0 ? h0 + tg.entry[g.chunk0] : kTileStride + ft.exit_cur[c - 1]); // where this parse starts (the batch's first tile: the chain's hand-over)
+    const uint32_t tok_from = warm ? h0 : 0u;                                                            // tokens in front of this position are the warm-up's
+    const uint32_t *ins_in = warm ? nullptr : (c == 0 ? ft.prev_ins : (ft.cur[c - 1] ? ft.ins1 : ft.ins0) + (size_t)(c - 1) * kInsWords);
+
+    for (uint32_t i = lane; i < kFwFlagWords; i += 64) flags[i] = 0;
+    __syncthreads();
+    if (ins_in) { // the history's bits, by S index: every position in front of the entry that the predecessor found in the chains
+        for (uint32_t q0 = 0; q0 < entry_pos; q0 += 256) {
+            uint32_t iv[4]; bool on[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t q = q0 + u * 64 + lane;
+                on[u] = q < entry_pos && q < npos && ((ins_in[q >> 5] >> (q & 31u)) & 1u);
+                iv[u] = on[u] ? ir[q] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) if (on[u]) { const uint32_t b = 65536u - (iv[u] & 0xffffu) - 1u; atomicOr(&flags[b >> 5], 1u << (b & 31u)); }
+        }
+    }
+
+    uint32_t filled = 0;
+    auto fill_to = [&](uint32_t need) {
+        while (filled < need) {
+            const uint32_t o = filled + 16 * lane;
+            uint4 v;
+            if ((uint64_t)o + 16 <= safe_end) v = reinterpret_cast<const FwU128 *>(src + o)->v; else v = fw_tail16(src, o, safe_end);
+            const uint32_t ro = fw_ring(filled) + 16 * lane;
+            *reinterpret_cast<uint4 *>(fw_lds + ro) = v;
+            if (ro < kFwMirror) *reinterpret_cast<uint4 *>(fw_lds + kFwRing + ro) = v;
+            filled += 1024;
+        }
+    };
+    auto load_ir = [&](uint32_t w) -> uint32_t { const uint32_t p = w * 64 + lane; return p < npos ? ir[p] : 0u; };
+    uint4 sq0, sq1, sq2, sq3;
+    auto load_s = [&](uint32_t iv) {
+        const uint32_t rk = iv >> 16;
+        const uint8_t *a = reinterpret_cast<const uint8_t *>(S) + 2 * (int)(iv & 0xffffu) - 64;
+        sq0 = sq1 = sq2 = sq3 = make_uint4(0, 0, 0, 0);
+        if (rk > 0) sq3 = reinterpret_cast<const FwU128 *>(a + 48)->v;
+        if (rk > 8) sq2 = reinterpret_cast<const FwU128 *>(a + 32)->v;
+        if (rk > 16) sq1 = reinterpret_cast<const FwU128 *>(a + 16)->v;
+        if (rk > 24) sq0 = reinterpret_cast<const FwU128 *>(a)->v;
+    };
+    uint32_t pos = entry_pos, ntok = 0, ent_used = ~0u, tail_from = ~0u;
+    const uint32_t win0 = pos / 64, nwin = (n + 63) / 64;
+    uint32_t ir_cur = load_ir(win0), ir_nxt = load_ir(win0 + 1);
+    load_s(ir_cur);
+    bool cross_short = false;
+    __syncthreads();
+
+    for (uint32_t win = win0; win < nwin && pos < h1; win++) {
+        const uint32_t w0 = win * 64, p = w0 + lane;
+        const bool skip = pos >= w0 + 64;
+        if (!skip) {
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 16) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 32) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 48) = sq3;
+        }
+        const uint32_t iv = ir_cur;
+        load_s(ir_nxt);
+        ir_cur = ir_nxt;
+        ir_nxt = load_ir(win + 2);
+        fill_to(w0 + 64 + kMaxMatch + NICE + 16 < kChunkMax + 1024 ? w0 + 64 + kMaxMatch + NICE + 16 : kChunkMax + 1024);
+        if (skip) continue;
+
+        const uint32_t idx = iv & 0xffffu, rk = iv >> 16;
+        const bool haspos = p < npos;
+        const uint32_t B0 = 65536u - idx;
+        const uint32_t own_w = (B0 - 1) >> 5, own_b = 1u << ((B0 - 1) & 31u);
+        const uint32_t entl = pos - w0;
+        if (haspos && (lane >= entl || cross_short)) atomicOr(&flags[own_w], own_b);
+        const uint32_t look = n > p ? n - p : 0, cap = look < kMaxMatch ? look : kMaxMatch, ni = (uint32_t)NICE < look ? (uint32_t)NICE : look;
+        const uint32_t cmp_max = cap < (uint32_t)NICE ? cap : (uint32_t)NICE;
+        const int w = (int)(p + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
+        uint64_t own[NW];
+        const uint32_t own_a = ring_a + fw_ring(p);
+        if (NW == 1) own[0] = fw_ld64(own_a);
+        else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        const uint32_t own_byte = (uint32_t)own[0] & 255u;
+
+        uint32_t res = 1, mstart = 0, mex = 0;
+        uint32_t lend = n - w0 < 64 ? n - w0 : 64;              // lanes of this window that are positions of the input ...
+        if (h1 - w0 < lend) lend = h1 - w0;                     // ... and of the tile's range: a token that starts at or behind h1 is the next tile's
+        auto read_bits = [&]() -> uint32_t {
+            const uint32_t wa = B0 >> 5, lo32 = flags[wa], hi32 = flags[wa + 1];
+            uint32_t m = __builtin_amdgcn_alignbit(hi32, lo32, B0 & 31u);
+            if (rk < 32) m &= (1u << rk) - 1u;
+            return m;
+        };
+
+        uint32_t start = entl;
+        bool need_eval = true, dirty = false;
+        for (;;) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (need_eval) dirty = false;
+            if (need_eval && lane >= start) {
+                res = 1; mstart = 0; mex = 0;
+                if (haspos && rk != 0) {
+                    uint32_t m = read_bits(), best = kMinMatch - 1, nsel = 0;
+                    bool first = true, stopped = false, term = false;
+#pragma unroll 1
+                    for (int g0 = 0; g0 < CHAIN; g0 += 4) {
+                        if (__builtin_amdgcn_ballot_w64(!stopped && m != 0) == 0) break;
+                        uint32_t k[4], q[4]; bool v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + kFwOffStg + lane * kFwStgStride + 62 - 2 * k[u]);
+                        uint64_t cb[4][NW];
+                        {
+                            const uint32_t a0 = ring_a + fw_ring(q[0]), a1 = ring_a + fw_ring(q[1]), a2 = ring_a + fw_ring(q[2]), a3 = ring_a + fw_ring(q[3]);
+#pragma unroll
+                            for (int t = 0; t < NW; t++) fw_ld64x4(a0 + 8 * t, a1 + 8 * t, a2 + 8 * t, a3 + 8 * t, cb[0][t], cb[1][t], cb[2][t], cb[3][t]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (v[u] && !stopped) {
+                                mex |= 1u << k[u];
+                                const int wq = (int)(q[u] + base);
+                                const bool far = first ? (wq <= 0 || (uint32_t)(w - wq) > kMaxDist || (p == nil_local && (uint32_t)(w - wq) == kMaxDist)) : wq <= limit;
+                                if (far) stopped = true;
+                                else {
+                                    first = false; nsel++;
+                                    uint32_t l = 0;
+#pragma unroll
+                                    for (int t = 0; t < NW; t++) if (l == 8u * t) l += fw_diff8(cb[u][t] ^ own[t]);
+                                    l = l < cmp_max ? l : cmp_max;
+                                    if (l > best) { best = l; mstart = q[u]; if (l >= ni) { stopped = true; term = l < cap; } }
+                                    if (nsel == (uint32_t)CHAIN) stopped = true;
+                                }
+                            }
+                        }
+                    }
+                    if (!first && best >= kMinMatch) res = best | (term ? kResTerm : 0u);
+                    if (!stopped && nsel < (uint32_t)CHAIN && rk > kFwDepth) res = kResInc;
+                }
+            }
+            const uint64_t nonlit = __builtin_amdgcn_ballot_w64(res != 1u);
+            uint32_t pk = (lane + (res & kResLen)) | (res & (kResTerm | kResInc));
+            const uint32_t len_e = res & kResLen;
+            const uint64_t longm = __builtin_amdgcn_ballot_w64(len_e >= kMinMatch && !(len_e <= max_insert && n - p - len_e >= kMinMatch));
+            uint64_t T = 0;
+            uint32_t L = start, stop_inc = 64, Llast = 64;
+            while (L < lend) {
+                const uint64_t ahead = (nonlit >> L) & (lend - L >= 64 ? ~0ull : (1ull << (lend - L)) - 1ull); // (a match behind the range's end starts no token of this tile)
+                if (ahead == 0) { T |= (~0ull << L) & (lend >= 64 ? ~0ull : (1ull << lend) - 1ull); L = lend; Llast = 64; break; }
+                const uint32_t run = (uint32_t)__builtin_ctzll(ahead);
+                T |= ((1ull << run) - 1ull) << L;
+                L += run;
+                uint32_t x = __builtin_amdgcn_readlane(pk, L);
+                if (x & (kResInc | kResTerm)) {
+                    if (x & kResInc) { stop_inc = L; break; }
+                    const uint32_t p0 = w0 + L, q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
+                    const uint32_t o = NICE + 4 * lane;
+                    uint32_t xa, xb;
+                    fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
+                    xa ^= xb;
+                    const uint64_t ne = __builtin_amdgcn_ballot_w64(xa != 0);
+                    uint32_t len = cap0;
+                    if (ne != 0) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(ne), xf = __builtin_amdgcn_readlane(xa, f);
+                        len = NICE + 4 * f + ((uint32_t)__builtin_ctz(xf) >> 3);
+                        len = len < cap0 ? len : cap0;
+                    }
+                    res = lane == L ? len : res;
+                    pk = lane == L ? L + len : pk;
+                    x = L + len;
+                }
+                T |= 1ull << L;
+                Llast = L;
+                L = x & kResLen;
+            }
+            bool cs_new = cross_short;
+            if (L >= 64 && Llast < 64) cs_new = !((longm >> Llast) & 1ull);
+            uint64_t C = 0;
+            {
+                const uint64_t below = T & lanes_below;
+                const uint32_t owner = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                const bool inside = below != 0 && !(T & lane_bit) && lane < L && ((longm >> owner) & 1ull);
+                C = __builtin_amdgcn_ballot_w64(inside);
+            }
+            if ((C & lane_bit) && haspos) atomicAnd(&flags[own_w], ~own_b);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            dirty = dirty || C != 0;
+            bool stale = false;
+            if (dirty && lane >= start && mex != 0) stale = (mex & ~read_bits()) != 0;
+            const uint64_t st_mask = __builtin_amdgcn_ballot_w64(stale) & T;
+            const uint32_t Lstale = st_mask ? (uint32_t)__builtin_ctzll(st_mask) : 64u;
+            const uint32_t Lacc = Lstale < stop_inc ? Lstale : stop_inc;
+            const uint64_t Tacc = Lacc >= 64 ? T : T & ((1ull << Lacc) - 1ull);
+            {   // the accepted tokens (the warm-up's, in front of h0, are dropped)
+                const uint32_t lo_l = tok_from > w0 ? (tok_from - w0 < 64 ? tok_from - w0 : 64u) : 0u;
+                const uint64_t Tv = lo_l >= 64 ? 0ull : Tacc & (~0ull << lo_l);
+                if (Tv & lane_bit) {
+                    const uint32_t ln = res & kResLen;
+                    tok[ntok + (uint32_t)__builtin_popcountll(Tv & lanes_below)] = ln == 1 ? tok_lit(own_byte) : tok_match(p - mstart, ln - kMinMatch);
+                }
+                if (ent_used == ~0u && Tv != 0) ent_used = w0 + (uint32_t)__builtin_ctzll(Tv) - h0;
+                ntok += (uint32_t)__builtin_popcountll(Tv);
+            }
+            if (Lacc >= 64 || Lacc >= lend) {
+                pos = w0 + L; cross_short = cs_new;
+                // the tile's last token, when it is a short match that reaches into the next window: its strings ARE in the chains (deflate.c:1510-1520), and no
+                // window of this tile will set their bits
+                tail_from = (L > 64 && Llast < 64 && !((longm >> Llast) & 1ull)) ? w0 + 64 : ~0u;
+                break;
+            }
+            if (lane >= Lacc && (C & lane_bit) && haspos) atomicOr(&flags[own_w], own_b);
+            start = Lacc;
+            if (Lstale <= stop_inc) { need_eval = true; continue; }
+            {   // the search at Lacc over its whole bucket, by all lanes
+                const uint32_t p0 = w0 + Lacc, i0 = __builtin_amdgcn_readlane(idx, Lacc), r0 = __builtin_amdgcn_readlane(rk, Lacc);
+                const uint32_t look0 = n - p0, cap0 = look0 < kMaxMatch ? look0 : kMaxMatch, ni0 = (uint32_t)NICE < look0 ? (uint32_t)NICE : look0;
+                const int w00 = (int)(p0 + base), limit0 = w00 > (int)kMaxDist ? w00 - (int)kMaxDist : 0;
+                uint32_t best = kMinMatch - 1, ms0 = 0, ch = CHAIN;
+                bool first = true, done = false;
+                const uint32_t pa = ring_a;
+                for (uint32_t k0 = 0; k0 < r0 && !done; k0 += 64) {
+                    const uint32_t kk = k0 + lane;
+                    const bool valid = kk < r0;
+                    const uint32_t q = valid ? S[(int)i0 - 1 - (int)kk] : 0u;
+                    const uint32_t rv = 65536u - i0 + kk;
+                    const bool ins = valid && ((flags[rv >> 5] >> (rv & 31u)) & 1u);
+                    uint32_t l = 0;
+                    if (ins && (int)(q + base) > limit0 - 1) {
+                        for (;;) {
+                            const uint32_t d = fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l)));
+                            l += d;
+                            if (d < 8 || l >= cap0) break;
+                        }
+                        l = l < cap0 ? l : cap0;
+                    }
+                    uint64_t im = __builtin_amdgcn_ballot_w64(ins);
+                    while (im) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(im); im &= im - 1;
+                        const uint32_t qf = __builtin_amdgcn_readlane(q, f), lf = __builtin_amdgcn_readlane(l, f);
+                        const int wq = (int)(qf + base);
+                        if (first ? (wq <= 0 || (uint32_t)(w00 - wq) > kMaxDist || (p0 == nil_local && (uint32_t)(w00 - wq) == kMaxDist)) : wq <= limit0) { done = true; break; }
+                        first = false;
+                        if (lf > best) { best = lf; ms0 = qf; if (lf >= ni0) { done = true; break; } }
+                        if (--ch == 0) { done = true; break; }
+                    }
+                }
+                const uint32_t r1 = (!first && best >= kMinMatch) ? best : 1u;
+                if (lane == Lacc) { res = r1; mstart = ms0; mex = 0; }
+            }
+            need_eval = false;
+        }
+    }
+    // ---- what the tile hands on: where its parse ends, which of its positions are in the chains ----
+    if (tail_from != ~0u && pos >= h1) { const uint32_t q = tail_from + lane; if (q < pos && q < npos) { const uint32_t b = 65536u - (ir[q] & 0xffffu) - 1u; atomicOr(&flags[b >> 5], 1u << (b & 31u)); } }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ent_used == ~0u) ent_used = (pos > h0 ? pos : h0) - h0; // (no token: the parse entered at or behind the range's end)
+    const uint32_t exit_k = (pos > h1 ? pos : h1) - h1;
+    const uint32_t *old_ins = (ft.cur[c] ? ft.ins1 : ft.ins0) + (size_t)c * kInsWords;
+    uint32_t *new_ins = (ft.cur[c] ? ft.ins0w : ft.ins1w) + (size_t)c * kInsWords;
+    bool diff = exit_k != ft.exit_cur[c];
+    uint32_t dbg_first = ~0u, dbg_last = 0, dbg_n = 0;
+    for (uint32_t q0 = kTileStride; q0 < kChunkMax; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        bool on = false;
+        if (q < pos && q < npos) { const uint32_t b = 65536u - (ir[q] & 0xffffu) - 1u; on = (flags[b >> 5] >> (b & 31u)) & 1u; }
+        const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+        const uint32_t wi = (q0 - kTileStride) >> 5;
+        if (lane == 0) {
+            const bool dw = old_ins[wi] != (uint32_t)m || old_ins[wi + 1] != (uint32_t)(m >> 32);
+            if (dw) { if (dbg_first == ~0u) dbg_first = q0; dbg_last = q0; dbg_n++; }
+            diff = diff || dw; new_ins[wi] = (uint32_t)m; new_ins[wi + 1] = (uint32_t)(m >> 32);
+        }
+    }
+    if (lane == 0 && ft.dbg) { uint32_t *d = ft.dbg + (size_t)c * 8; d[0] = ft.round; d[1] = dbg_n; d[2] = dbg_first; d[3] = dbg_last; d[4] = exit_k; d[5] = ft.exit_cur[c]; d[6] = entry_pos; d[7] = ntok; }
+    if (lane == 0) {
+        meta[c].ntok = ntok; meta[c].in_bytes = 0;
+        tg.entry[g.chunk0 + c] = (uint16_t)ent_used;
+        ft.exit_new[c] = (uint16_t)exit_k;
+        ft.changed[c] = diff ? 1 : 0;
+    }
+}
+
 // the levels' own parameters only (deflate.c:137-149): a tuned stream goes to the lane-per-chunk loop
 bool lz_fastwin_serves(const LevelCfg &cfg)
 {
@@ -408,6 +723,82 @@ void launch_lz_fastwin(const ChunkGeom &g, LevelCfg cfg, const uint16_t *S, cons
     if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_kernel<4, 8>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
     else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_kernel<8, 16>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
     else hipLaunchKernelGGL((fastwin_kernel<32, 32>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+}
+
+// ---- the rounds' bookkeeping (one lane per tile) ----
+__global__ void __launch_bounds__(256) fast_init_kernel(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { cur[i] = 0; active[i] = 1; exit_cur[i] = 0xffffu; }
+}
+// behind a round: the tiles that were parsed make their new results current; a tile is parsed again when its predecessor's results have changed
+__global__ void __launch_bounds__(256) fast_flip_kernel(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new,
+                                                        uint32_t n, uint32_t round, uint32_t *count)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (round == 0 || active[i]) { cur[i] ^= 1; exit_cur[i] = exit_new[i]; }
+    const bool nx = i >= 1 && (round == 0 || (active[i - 1] && changed[i - 1]));
+    active_next[i] = nx ? 1 : 0;
+    if (nx) atomicAdd(count, 1u);
+}
+// behind the last round of a batch: the entry of the tile behind the batch, and the batch's last bits as the next batch's history
+__global__ void __launch_bounds__(256) fast_finish_kernel(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after,
+                                                          uint32_t *prev_ins, uint32_t *prev_prev_ins)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) *entry_after = exit_cur[n - 1];
+    // (the bits in front of the last tile: the tile before it, or what was in front of the batch -- kept for the feed's hand-over, fast_hist_kernel)
+    if (n >= 2) { const uint32_t *b = (cur[n - 2] ? ins1 : ins0) + (size_t)(n - 2) * kInsWords; for (uint32_t i = tid; i < kInsWords; i += 256) prev_prev_ins[i] = b[i]; }
+    else for (uint32_t i = tid; i < kInsWords; i += 256) prev_prev_ins[i] = prev_ins[i];
+    __syncthreads();
+    const uint32_t *a = (cur[n - 1] ? ins1 : ins0) + (size_t)(n - 1) * kInsWords;
+    for (uint32_t i = tid; i < kInsWords; i += 256) prev_ins[i] = a[i];
+}
+// the feed's hand-over: "in the chains" for the 32512 positions in front of where the parse stands (bit j: position new_w0 + j), from the bits of the
+// last tile (its local positions 32512 ..) and of what lay in front of it (its local positions 0 .. 33023).  x0: new_w0 in the last tile's local coordinates.
+__global__ void __launch_bounds__(256) fast_hist_kernel(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out)
+{
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= kInsWords) return;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        const uint32_t j = w * 32 + b, x = x0 + j;
+        if (j >= count) break;
+        const bool on = x < kTileStride ? ((before[x >> 5] >> (x & 31u)) & 1u) : x < kChunkMax ? ((last[(x - kTileStride) >> 5] >> ((x - kTileStride) & 31u)) & 1u) : false;
+        v |= (on ? 1u : 0u) << b;
+    }
+    out[w] = v;
+}
+void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st) { hipLaunchKernelGGL(fast_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, exit_cur, n); }
+void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
+                      uint32_t *count, hipStream_t st)
+{
+    hipMemsetAsync(count, 0, 4, st);
+    hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count);
+}
+void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
+                        hipStream_t st)
+{
+    hipLaunchKernelGGL(fast_finish_kernel, dim3(1), dim3(256), 0, st, cur, exit_cur, ins0, ins1, n, entry_after, prev_ins, prev_prev_ins);
+}
+void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(fast_hist_kernel, dim3((kInsWords + 255) / 256), dim3(256), 0, st, before, last, x0, count, out);
+}
+
+void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+{
+    static bool opt_in = false;
+    if (!opt_in) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        opt_in = true;
+    }
+    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
 }
 
 } // namespace zgpu

@@ -1418,6 +1418,31 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
 // A batch of tiles of a continuous stream (zgpu_cont.hip): sort, walkers + exit functions, the chain of entries, the tiles' tokens.
 void launch_chain(const uint16_t *exits, uint32_t ntiles, uint16_t *comp, uint16_t *gentry, uint16_t *entry, hipStream_t st);
 void launch_parse_tile(const ChunkGeom &g, LevelCfg cfg, const uint32_t *gm, const uint32_t *gs, uint32_t *tokens, ChunkMeta *meta, const TileGeom &tg, hipStream_t st);
+// the sort alone (levels 1-3 go on with fastwin_tile_kernel's rounds, zgpu_engine.hip): where S and ir of the batch's tiles are
+void launch_sort_tiles(const ChunkGeom &g, void *workspace, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, const uint16_t **S_out, const uint32_t **ir_out)
+{
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    const size_t nch = g.nchunks;
+    uint32_t *fault = reinterpret_cast<uint32_t *>(w);
+    uint16_t *S = reinterpret_cast<uint16_t *>(w + 256);
+    uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
+    uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
+    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * kHeadStride);
+    uint32_t *ir = reinterpret_cast<uint32_t *>(recs + nch * kChunkMax);
+    hipEvent_t ev{};
+    prof_span_begin(prof, st, &ev);
+    static int sort_env = -1;
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (exact_sort || sort_env == 1) {
+        hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
+        hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
+    } else {
+        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st);
+    }
+    prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
+    *S_out = S; *ir_out = ir;
+}
 void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, uint16_t *comp, uint16_t *gentry, hipStream_t st,
                      void *prof, int exact_sort)
 {

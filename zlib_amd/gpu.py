@@ -80,7 +80,7 @@ def load_library():
     L.zgpu_deflate_host.argtypes = [vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_cont_bound.argtypes = [u64]
     L.zgpu_deflate_cont_bound.restype = u64
-    L.zgpu_deflate_cont_host.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(_Params), C.c_int, C.POINTER(ContState), vp, vp, u32, vp, u64, C.POINTER(DeflateResult)]
+    L.zgpu_deflate_cont_host.argtypes = [vp, vp, u64, vp, u64, u64, C.POINTER(_Params), C.c_int, C.POINTER(ContState), vp, vp, vp, u32, vp, u64, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_host.argtypes = [vp, vp, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult)]
     L.zgpu_deflate_segments_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(_Params), vp, u64, vp, C.POINTER(DeflateResult), vp]
     L.zgpu_inflate_device.argtypes = [vp, vp, u64, vp, u64, u32, vp, u64, C.POINTER(InflateResult), vp]
@@ -191,7 +191,7 @@ class Engine:
         """State of a fresh continuous stream (no dictionary) + its token carry."""
         import numpy as np
         cs = ContState(0, 0, 0, 0, 0, 0, 2, 1, 8)
-        return cs, np.zeros(16384, dtype=np.uint32)
+        return cs, (np.zeros(16384, dtype=np.uint32), np.zeros(1040, dtype=np.uint32))  # the block's tokens so far; which history positions are in the chains (levels 1-3)
 
     def deflate_cont_host(self, buf, check_from, level, mode, cs, carry, strategy=0, flags=0, excl=(), split=None):
         """One feed of a continuous stream (zgpu_deflate_cont_host): buf = the history the parse can still reach + the unparsed bytes, buf[0] at stream
@@ -206,8 +206,8 @@ class Engine:
         p = _Params(level, 0, flags, LZ_AUTO, strategy, 0)
         res = DeflateResult()
         ex = np.ascontiguousarray(list(excl) + [0], dtype=np.uint64)
-        self._check(self.L.zgpu_deflate_cont_host(self.h, arr.ctypes.data, split, arr.ctypes.data + split, n - split, check_from, C.byref(p), mode, C.byref(cs), carry.ctypes.data,
-                                                  ex.ctypes.data, len(excl), out.ctypes.data, cap, C.byref(res)))
+        self._check(self.L.zgpu_deflate_cont_host(self.h, arr.ctypes.data, split, arr.ctypes.data + split, n - split, check_from, C.byref(p), mode, C.byref(cs), carry[0].ctypes.data,
+                                                  carry[1].ctypes.data, ex.ctypes.data, len(excl), out.ctypes.data, cap, C.byref(res)))
         self.last = res
         return out[: res.out_bytes].tobytes()
 

@@ -265,7 +265,8 @@ struct internal_state {
                              still be stored) and everything that has not been parsed yet */
     uint64_t win_abs0;
     zgpu_cont_state cs;
-    uint32_t *carry;      /* the tokens of the block that is filling (ZGPU_CONT_CARRY_TOKENS words) */
+    uint32_t *carry;      /* the tokens of the block that is filling (ZGPU_CONT_CARRY_TOKENS words), then ZGPU_CONT_HIST_WORDS words: which positions of the
+                             history are in the hash chains (levels 1-3) */
     uint64_t *excl; uint32_t nexcl, excl_cap; /* stream positions that are in no hash chain: the two in front of every flush point (and of the dictionary's end) */
     uint64_t floor_pos;   /* nothing in front of this position is history any more (Z_FULL_FLUSH: CLEAR_HASH, deflate.c:817) */
     uint64_t fed;         /* stream position behind the last byte received (dictionary bytes count) */
@@ -367,8 +368,8 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     s->wrap = wrap; s->level = level; s->strategy = strategy; s->w_bits = windowBits; s->mem_level = memLevel;
     /* one continuous stream at the default geometry; another windowBits / memLevel is served in independent chunks.
      * (levels 1-3: the continuous deflate_fast is served since round 4 as well) */
-    s->cont = !chunks_mode() && windowBits == 15 && memLevel == 8 && (level == 0 || level >= 4 || getenv("ZAMD_CONT_FAST"));
-    if (s->cont) { s->carry = (uint32_t *)malloc((size_t)ZGPU_CONT_CARRY_TOKENS * 4); if (!s->carry) { state_free(strm); return Z_MEM_ERROR; } }
+    s->cont = !chunks_mode() && windowBits == 15 && memLevel == 8;
+    if (s->cont) { s->carry = (uint32_t *)calloc((size_t)ZGPU_CONT_CARRY_TOKENS + ZGPU_CONT_HIST_WORDS + 8, 4); if (!s->carry) { state_free(strm); return Z_MEM_ERROR; } }
     return deflateReset(strm);
 }
 EXPORT int deflateInit_(z_streamp strm, int level, const char *version, int stream_size)
@@ -386,6 +387,7 @@ EXPORT int deflateReset(z_streamp strm)
     s->adler = 1; s->crc = 0; strm->adler = s->wrap == 2 ? 0 : 1; /* deflate.c:374-378 */
     s->win.len = 0; s->win_abs0 = 0; s->nexcl = 0; s->floor_pos = 0; s->fed = 0; s->checked = 0; s->tail_adler = 1; s->tail_crc = 0;
     s->st_str = s->st_blk = s->st_off = 0;
+    if (s->carry) memset(s->carry + ZGPU_CONT_CARRY_TOKENS, 0, ((size_t)ZGPU_CONT_HIST_WORDS + 8) * 4);
     memset(&s->cs, 0, sizeof s->cs); s->cs.data_type = 2; s->cs.first_block = 1; s->cs.last_eob = 8; /* _tr_init, trees.c:382-406 */
     return Z_OK;
 }
@@ -414,6 +416,7 @@ EXPORT int deflateSetDictionary(z_streamp strm, const Bytef *d, uInt n)
         if (!buf_put(&s->win, d + (n - keep), keep)) return Z_MEM_ERROR;
         s->fed = s->checked = keep; s->cs.entry = s->cs.block_start = keep; s->st_str = s->st_blk = keep; s->st_off = 0; s->nexcl = 0;
         if (!excl_add(s, keep - 2) || !excl_add(s, keep - 1)) return Z_MEM_ERROR;
+        for (uInt j = 0; j + 2 < keep; j++) s->carry[ZGPU_CONT_CARRY_TOKENS + (j >> 5)] |= 1u << (j & 31u); /* levels 1-3: the same as bits */
         s->dict_pending = s->wrap ? 1 : 0; /* (only the header's PRESET_DICT flag and DICTID look at it) */
         return Z_OK;
     }
@@ -440,7 +443,7 @@ EXPORT int deflateParams(z_streamp strm, int level, int strategy)
         else if ((level != s->level || strategy != s->strategy) && s->level != 0 && s->fed - s->cs.entry > 1024 && s->status != ST_FINISH) rc = cont_feed(strm, NULL, 0, ZGPU_CONT_MORE);
         if (f_old != f_new) {
             if (f_new == 0) { s->st_str = s->st_blk = s->fed; s->st_off = s->fed >= 65275u ? ((s->fed - 65275u) / 32768u + 1u) * 32768u : 0; s->cs.entry = s->fed; }
-            else if (f_old == 0) { s->cs.entry = s->cs.block_start = s->fed; s->floor_pos = s->fed; if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
+            else if (f_old == 0) { s->cs.entry = s->cs.block_start = s->fed; s->floor_pos = s->fed; memset(s->carry + ZGPU_CONT_CARRY_TOKENS, 0, (size_t)ZGPU_CONT_HIST_WORDS * 4); if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
         }
         if (s->level != level) s->tuned = 0;
         s->level = level; s->strategy = strategy;
@@ -500,7 +503,7 @@ static int state_copy(z_streamp dest, z_streamp source, int kind)
     dest->state = ds;
     ds->carry = NULL; ds->excl = NULL; ds->excl_cap = 0;
     int ok = buf_dup(&ds->in, &ss->in) && buf_dup(&ds->out, &ss->out) && buf_dup(&ds->dict, &ss->dict) && buf_dup(&ds->win, &ss->win);
-    if (ok && ss->carry) { ds->carry = (uint32_t *)malloc((size_t)ZGPU_CONT_CARRY_TOKENS * 4); ok = ds->carry != NULL; if (ok) memcpy(ds->carry, ss->carry, (size_t)ZGPU_CONT_CARRY_TOKENS * 4); }
+    if (ok && ss->carry) { const size_t cb = ((size_t)ZGPU_CONT_CARRY_TOKENS + ZGPU_CONT_HIST_WORDS + 8) * 4; ds->carry = (uint32_t *)malloc(cb); ok = ds->carry != NULL; if (ok) memcpy(ds->carry, ss->carry, cb); }
     if (ok && ss->nexcl) { ds->excl = (uint64_t *)malloc((size_t)ss->nexcl * sizeof(uint64_t)); ok = ds->excl != NULL; if (ok) { memcpy(ds->excl, ss->excl, (size_t)ss->nexcl * sizeof(uint64_t)); ds->excl_cap = ss->nexcl; } }
     if (!ok) {
         free(ds->in.p); free(ds->out.p); free(ds->dict.p); free(ds->win.p); free(ds->carry); free(ds->excl); dest->zfree(dest->opaque, ds); dest->state = Z_NULL;
@@ -654,7 +657,7 @@ static int cont_feed(z_streamp strm, const uint8_t *in, size_t n, int mode)
     s->cs.abs0 = s->win_abs0;
     zgpu_engine *e = engine_checkout();
     zgpu_deflate_set_tuning(e, s->tuned, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
-    const int rc = zgpu_deflate_cont_host(e, s->win.p, s->win.len, in, n, s->checked - s->win_abs0, &p, mode, &s->cs, s->carry, s->excl, s->nexcl, s->out.p + s->out.len, cap, &r);
+    const int rc = zgpu_deflate_cont_host(e, s->win.p, s->win.len, in, n, s->checked - s->win_abs0, &p, mode, &s->cs, s->carry, s->carry + ZGPU_CONT_CARRY_TOKENS, s->excl, s->nexcl, s->out.p + s->out.len, cap, &r);
     zgpu_deflate_set_tuning(e, 0, 0, 0, 0, 0);
     engine_checkin(e);
     if (rc != ZGPU_OK) { strm->msg = (char *)zgpu_engine_error(e); return rc == ZGPU_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR; }
@@ -757,7 +760,7 @@ static int cont_deflate(z_streamp strm, int flush)
     if (rc != Z_OK) return rc;
     if (flush != Z_FINISH) {
         if (!cont_marker(s, flush)) return Z_MEM_ERROR;
-        if (flush == Z_FULL_FLUSH) { s->floor_pos = s->fed; s->nexcl = 0; if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
+        if (flush == Z_FULL_FLUSH) { s->floor_pos = s->fed; s->nexcl = 0; memset(s->carry + ZGPU_CONT_CARRY_TOKENS, 0, (size_t)ZGPU_CONT_HIST_WORDS * 4); if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
         else if ((s->fed >= 2 && !excl_add(s, s->fed - 2)) || (s->fed >= 1 && !excl_add(s, s->fed - 1))) return Z_MEM_ERROR; /* never inserted: lookahead < MIN_MATCH there (deflate.c:1576) */
     }
     cont_checks_done(strm);
