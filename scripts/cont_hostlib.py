@@ -14,7 +14,7 @@ def main():
     rnd = random.Random(17)
     bad = 0
     hello = (b"hello, hello! " * 80000)[:1 << 20]
-    for level in (6, 9, 4, 0):
+    for level in (6, 9, 4, 0, 1, 2, 3):
         rc, got = Z.compress2(hello, level)
         want = R.compress2(hello, level)
         ok = rc == 0 and got == want
@@ -34,7 +34,7 @@ def main():
             plan.append((n, 4 if pos == len(d) else rnd.choice([0, 0, 0, 1, 2, 3])))
         plans.append(plan)
     for plan in plans:
-        for level, wbits in ((6, 15), (9, -15), (4, 31), (0, 15)):
+        for level, wbits in ((6, 15), (9, -15), (4, 31), (0, 15), (1, 15), (2, -15), (3, 31)):
             for in_step, out_step in ((None, None), (30011, 4099)):
                 calls = []; pos = 0
                 for n, f in plan:

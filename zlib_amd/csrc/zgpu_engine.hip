@@ -40,7 +40,7 @@ void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
                       uint32_t *count, hipStream_t st);
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
-                        hipStream_t st);
+                        const uint32_t *low, hipStream_t st);
 void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st);
 void launch_cont_tokens(const ChunkGeom &g, const TileGeom &tg, const uint32_t *tokens, const ChunkMeta *tmeta, ContState *st, uint32_t *tokoff, const uint32_t *carry, uint32_t *T,
                         ContBlk *blk, uint64_t seg_end, bool final_block, uint64_t sp, uint32_t nblk_cap, bool slow, hipStream_t s);
@@ -573,7 +573,7 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
     for (uint32_t round = 0;; round++) {
         FastTiles ft{};
         ft.exit_cur = e->cf_exit_a; ft.exit_new = e->cf_exit_b; ft.ins0 = ft.ins0w = e->cf_ins0; ft.ins1 = ft.ins1w = e->cf_ins1; ft.cur = e->cf_cur; ft.active = act; ft.changed = e->cf_changed;
-        ft.prev_ins = e->cf_prev; ft.round = round;
+        ft.prev_ins = e->cf_prev; ft.round = round; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
         static uint32_t *dbg = nullptr;
         const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
         if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
@@ -599,7 +599,7 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
         e->cf_tile_parses += active;
         uint8_t *x = act; act = act_next; act_next = x;
     }
-    launch_fast_finish(e->cf_cur, e->cf_exit_a, e->cf_ins0, e->cf_ins1, nb, tg.entry + g.chunk0 + nb, e->cf_prev, e->cf_prev2, st);
+    launch_fast_finish(e->cf_cur, e->cf_exit_a, e->cf_ins0, e->cf_ins1, nb, tg.entry + g.chunk0 + nb, e->cf_prev, e->cf_prev2, g.chunk0 == 0 ? e->cf_hist : nullptr, st);
     return ZGPU_OK;
 }
 
@@ -644,7 +644,7 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     }
     const uint64_t seg_end = ends ? cs->abs0 + f.buf_bytes : ~0ull, sp = ends ? cont_special_pos(seg_end) : ~0ull;
     uint32_t nexcl_dev = 0;
-    if (f.nexcl) {
+    if (f.nexcl && cfg.slow) { // (levels 1-3 know which positions are in the chains bit by bit: hist bits)
         if (f.nexcl > e->ct_excl_cap) { hipFree(e->ct_excl); e->ct_excl = nullptr; e->ct_excl_cap = 0; if ((rc = dev_alloc(e, &e->ct_excl, (size_t)f.nexcl + 64))) return rc; e->ct_excl_cap = f.nexcl + 64; }
         std::vector<uint64_t> off(f.nexcl);
         uint32_t k = 0;

@@ -695,6 +695,16 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
             diff = diff || dw; new_ins[wi] = (uint32_t)m; new_ins[wi + 1] = (uint32_t)(m >> 32);
         }
     }
+    if (c == 0 && g.chunk0 == 0 && ft.low_out) { // (uniform)
+        for (uint32_t q0 = 0; q0 < kTileStride; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            bool on = false;
+            if (q < pos && q < npos) { const uint32_t b = 65536u - (ir[q] & 0xffffu) - 1u; on = (flags[b >> 5] >> (b & 31u)) & 1u; }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+            if (lane == 0) { ft.low_out[q0 >> 5] = (uint32_t)m; ft.low_out[(q0 >> 5) + 1] = (uint32_t)(m >> 32); }
+        }
+        for (uint32_t i = kTileStride / 32 + lane; i < kInsWords; i += 64) ft.low_out[i] = 0;
+    }
     if (lane == 0 && ft.dbg) { uint32_t *d = ft.dbg + (size_t)c * 8; d[0] = ft.round; d[1] = dbg_n; d[2] = dbg_first; d[3] = dbg_last; d[4] = exit_k; d[5] = ft.exit_cur[c]; d[6] = entry_pos; d[7] = ntok; }
     if (lane == 0) {
         meta[c].ntok = ntok; meta[c].in_bytes = 0;
@@ -744,13 +754,13 @@ __global__ void __launch_bounds__(256) fast_flip_kernel(uint8_t *cur, const uint
 }
 // behind the last round of a batch: the entry of the tile behind the batch, and the batch's last bits as the next batch's history
 __global__ void __launch_bounds__(256) fast_finish_kernel(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after,
-                                                          uint32_t *prev_ins, uint32_t *prev_prev_ins)
+                                                          uint32_t *prev_ins, uint32_t *prev_prev_ins, const uint32_t *low)
 {
     const uint32_t tid = threadIdx.x;
     if (tid == 0) *entry_after = exit_cur[n - 1];
     // (the bits in front of the last tile: the tile before it, or what was in front of the batch -- kept for the feed's hand-over, fast_hist_kernel)
     if (n >= 2) { const uint32_t *b = (cur[n - 2] ? ins1 : ins0) + (size_t)(n - 2) * kInsWords; for (uint32_t i = tid; i < kInsWords; i += 256) prev_prev_ins[i] = b[i]; }
-    else for (uint32_t i = tid; i < kInsWords; i += 256) prev_prev_ins[i] = prev_ins[i];
+    else for (uint32_t i = tid; i < kInsWords; i += 256) prev_prev_ins[i] = low ? low[i] : prev_ins[i]; // (the feed's first tile: its own account of its positions 0 .. 32511)
     __syncthreads();
     const uint32_t *a = (cur[n - 1] ? ins1 : ins0) + (size_t)(n - 1) * kInsWords;
     for (uint32_t i = tid; i < kInsWords; i += 256) prev_ins[i] = a[i];
@@ -778,9 +788,9 @@ void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next,
     hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count);
 }
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
-                        hipStream_t st)
+                        const uint32_t *low, hipStream_t st)
 {
-    hipLaunchKernelGGL(fast_finish_kernel, dim3(1), dim3(256), 0, st, cur, exit_cur, ins0, ins1, n, entry_after, prev_ins, prev_prev_ins);
+    hipLaunchKernelGGL(fast_finish_kernel, dim3(1), dim3(256), 0, st, cur, exit_cur, ins0, ins1, n, entry_after, prev_ins, prev_prev_ins, low);
 }
 void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st)
 {
