@@ -339,6 +339,10 @@ static uint32_t best_match(enc *e, uint32_t p, uint32_t cur, uint32_t prev_lengt
     do {
         uint32_t q = cur - e->base + e->off, l = 0;
         while (l < cap && e->in[q + l] == e->in[p + l]) l++;
+        /* (the quick check, deflate.c:1121-1124, looks at the bytes best_len - 1 and best_len of the candidate: implied by l > best -- except with a seed of 0,
+         *  which deflate_fast can inherit from deflate_slow through deflateParams: then the byte IN FRONT of the candidate must equal the one in front of p) */
+        if (l < 2) l = 0; /* (the first two bytes are compared outright, deflate.c:1123-1124: a shorter prefix is no candidate even for a seed below 2) */
+        if (best == 0 && (q == 0 || p == 0 || e->in[q - 1] != e->in[p - 1])) l = 0;
         if (l > best) { *match_start = q; best = l; if (l >= nice) break; }
     } while ((cur = e->prev[cur & WMASK]) > limit && --chain != 0);
     return best <= look ? best : look;
@@ -526,6 +530,7 @@ typedef struct {
     uint32_t filled;   /* strstart + lookahead: end of the bytes read into the window */
     uint32_t avail;    /* end of the bytes the caller has handed over so far (next_in + avail_in) */
     uint32_t match_len, match_start; int pending; /* deflate_slow's match_length, match_start, match_available (they live in the state, deflate.h:152-160) */
+    uint32_t prev_length; /* s->prev_length: deflate_slow's; deflate_fast never sets it but longest_match seeds its search with it (deflate.c:1035), 2 in a stream that has always been fast */
 } cstate;
 
 static void cont_fill(enc *e, cstate *c) /* fill_window */
@@ -553,7 +558,7 @@ static int cont_slow(enc *e, cstate *c, int flush)
         const uint32_t look = c->filled - c->p, p = c->p;
         e->n = c->filled;
         if (look >= MINM) hash_head = insert_at(e, p);
-        prev_len = c->match_len; prev_match = c->match_start; c->match_len = MINM - 1;
+        prev_len = c->match_len; prev_match = c->match_start; c->match_len = MINM - 1; c->prev_length = prev_len;
         if (hash_head != 0 && prev_len < e->cfg->lazy && widx(e, p) - hash_head <= (uint32_t)MAXDIST) {
             if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) c->match_len = best_match(e, p, hash_head, prev_len, &c->match_start);
             else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) c->match_len = fast_match(e, p, hash_head, &c->match_start);
@@ -563,7 +568,7 @@ static int cont_slow(enc *e, cstate *c, int flush)
             uint32_t max_insert = p + look - MINM, k = prev_len - 2, q = p;
             cut = note_match(e, p - 1 - prev_match, prev_len - MINM);
             do { if (++q <= max_insert) hash_head = insert_at(e, q); } while (--k != 0);
-            c->pending = 0; c->match_len = MINM - 1; c->p = q + 1;
+            c->pending = 0; c->match_len = MINM - 1; c->p = q + 1; c->prev_length = 0; /* (the insertion loop counts s->prev_length down to 0, deflate.c:1630-1636) */
             if (cut) close_block(e, c->p, 0);
         } else if (c->pending) {
             cut = note_literal(e, e->in[p - 1]);
@@ -590,7 +595,7 @@ static int cont_fast(enc *e, cstate *c, int flush)
         e->n = c->filled;
         if (look >= MINM) hash_head = insert_at(e, p);
         if (hash_head != 0 && widx(e, p) - hash_head <= (uint32_t)MAXDIST) {
-            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) c->match_len = best_match(e, p, hash_head, MINM - 1, &c->match_start);
+            if (e->strategy != ORA_HUFFMAN_ONLY && e->strategy != ORA_RLE) c->match_len = best_match(e, p, hash_head, c->prev_length, &c->match_start);
             else if (e->strategy == ORA_RLE && widx(e, p) - hash_head == 1) c->match_len = fast_match(e, p, hash_head, &c->match_start);
         }
         if (c->match_len >= MINM) {
@@ -643,6 +648,15 @@ static void cont_align(enc *e) /* _tr_align, trees.c:892-915; the bit sink holds
 size_t ora_deflate_cont(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds, size_t ncuts,
                         uint8_t *out, size_t cap)
 {
+    return ora_deflate_cont_p(in, n, dict_len, level, strategy, cuts, kinds, NULL, NULL, ncuts, out, cap);
+}
+
+/* The same with deflateParams() (deflate.c:416-451) in front of some calls: plevel[k] / pstrategy[k] >= 0 are set before call k (k == ncuts: before the
+ * Z_FINISH call; the arrays hold ncuts + 1 entries; -1: no change).  A change of the compress function flushes what has been read with Z_PARTIAL_FLUSH
+ * first, any other change takes effect where the loop stands. */
+size_t ora_deflate_cont_p(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds,
+                          const int32_t *plevel, const int32_t *pstrategy, size_t ncuts, uint8_t *out, size_t cap)
+{
     if (n >= 0xfff00000u || dict_len > n || (dict_len != 0 && (dict_len < MINM || dict_len > MAXDIST))) return 0;
     if (level < 0 || level > 9 || strategy < 0 || strategy > ORA_FIXED) return 0;
     make_tables();
@@ -654,9 +668,19 @@ size_t ora_deflate_cont(const uint8_t *in, size_t n, size_t dict_len, int level,
     e->start = (uint32_t)dict_len; e->block_start = e->start;
     for (uint32_t q = 0; q + MINM <= e->start; q++) insert_at(e, q);
     cstate c; memset(&c, 0, sizeof c);
-    c.p = c.filled = c.avail = (uint32_t)dict_len; c.match_len = MINM - 1;
+    c.p = c.filled = c.avail = (uint32_t)dict_len; c.match_len = MINM - 1; c.prev_length = MINM - 1; /* lm_init, deflate.c:1003-1005 */
     int prev_flush = 0;
     for (size_t k = 0; k <= ncuts; k++) {
+        if (plevel && pstrategy && (plevel[k] >= 0 || pstrategy[k] >= 0)) { /* deflateParams */
+            const int nl = plevel[k] >= 0 ? plevel[k] : e->level, ns = pstrategy[k] >= 0 ? pstrategy[k] : e->strategy;
+            if (nl > 9 || ns > ORA_FIXED) { free(e); return 0; }
+            if (LEVELS[nl].mode != e->cfg->mode && c.avail != (uint32_t)dict_len && prev_flush < 1) { /* func changes and total_in != 0: deflate(strm, Z_PARTIAL_FLUSH) -- which answers Z_BUF_ERROR and does nothing right behind another flush (deflate.c:774-777; no input is pending here) */
+                const int done = e->cfg->mode == 2 ? cont_slow(e, &c, 1) : e->cfg->mode == 1 ? cont_fast(e, &c, 1) : cont_stored(e, &c, 1);
+                if (done) cont_align(e);
+                prev_flush = 1;
+            }
+            e->level = nl; e->strategy = ns; e->cfg = &LEVELS[nl];
+        }
         const int flush = k == ncuts ? 4 : kinds[k];
         const uint32_t upto = k == ncuts ? (uint32_t)n : (uint32_t)dict_len + cuts[k];
         if (upto < c.avail || upto > n || flush < 0 || flush > 4 || (k < ncuts && flush == 4)) { free(e); return 0; }

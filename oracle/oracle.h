@@ -75,6 +75,9 @@ size_t ora_deflate_bound(size_t n, size_t chunk_size);
 size_t ora_deflate_cont(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds, size_t ncuts,
                         uint8_t *out, size_t cap);
 
+size_t ora_deflate_cont_p(const uint8_t *in, size_t n, size_t dict_len, int level, int strategy, const uint32_t *cuts, const int32_t *kinds,
+                          const int32_t *plevel, const int32_t *pstrategy, size_t ncuts, uint8_t *out, size_t cap);
+
 /* adler32.c:57-125 and :128-149 */
 uint32_t ora_adler32(uint32_t adler, const uint8_t *buf, size_t len);
 uint32_t ora_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);

@@ -43,6 +43,8 @@ def lib():
         L.ora_deflate_stream.restype = C.c_size_t
         L.ora_deflate_cont.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ora_deflate_cont.restype = C.c_size_t
+        L.ora_deflate_cont_p.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ora_deflate_cont_p.restype = C.c_size_t
         L.ora_deflate_bound.argtypes = [C.c_size_t, C.c_size_t]
         L.ora_deflate_bound.restype = C.c_size_t
         L.ora_adler32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
@@ -150,9 +152,24 @@ def inflate_zlib(data: bytes, outcap: int):
     return _inflate(lib().ora_inflate_zlib, data, outcap)
 
 
-def deflate_cont(data: bytes, level: int, calls=(), strategy: int = 0, dictionary: bytes = b"") -> bytes:
-    """The continuous raw stream (ora_deflate_cont): calls = [(upto, flush), ...] as in refzlib.deflate_calls; the Z_FINISH call is implied."""
+def deflate_cont(data: bytes, level: int, calls=(), strategy: int = 0, dictionary: bytes = b"", params=None) -> bytes:
+    """The continuous raw stream (ora_deflate_cont): calls = [(upto, flush), ...] as in refzlib.deflate_calls; the Z_FINISH call is implied.
+    params: {call index: (level, strategy)} -- deflateParams() in front of that call (len(calls): in front of the Z_FINISH call)."""
     L = lib()
+    if params:
+        d = dictionary[-32506:] if dictionary and len(dictionary) >= 3 else b""
+        buf = d + data
+        n1 = len(calls) + 1
+        cuts = (C.c_uint32 * n1)(*([u for u, _ in calls] + [0]))
+        kinds = (C.c_int32 * n1)(*([f for _, f in calls] + [0]))
+        pl = (C.c_int32 * n1)(*[params.get(k, (-1, -1))[0] for k in range(n1)])
+        ps = (C.c_int32 * n1)(*[params.get(k, (-1, -1))[1] for k in range(n1)])
+        cap = len(data) + (len(data) >> 3) + 64 * (len(calls) + 2) + 1024
+        out = C.create_string_buffer(cap)
+        n = L.ora_deflate_cont_p(buf, len(buf), len(d), level, strategy, cuts, kinds, pl, ps, len(calls), out, cap)
+        if n == 0:
+            raise RuntimeError("oracle deflate_cont_p failed")
+        return out.raw[:n]
     d = dictionary[-32506:] if dictionary and len(dictionary) >= 3 else b""
     buf = d + data
     cuts = (C.c_uint32 * max(len(calls), 1))(*[u for u, _ in calls])
@@ -163,3 +180,28 @@ def deflate_cont(data: bytes, level: int, calls=(), strategy: int = 0, dictionar
     if n == 0:
         raise RuntimeError("oracle deflate_cont failed")
     return out.raw[:n]
+
+
+def cont_stream(data: bytes, level: int, calls=(), wbits: int = 15, strategy: int = 0, dictionary: bytes = None) -> bytes:
+    """What the reference's deflate() writes for ONE stream driven by `calls` = [(upto, flush), ...] (the Z_FINISH call is implied; () is compress2):
+    the header deflate() writes for these windowBits (15 zlib, -15 raw, 31 gzip without a gz_header; deflate.c:578-649), the continuous raw stream
+    (ora_deflate_cont) and the trailer (deflate.c:833-855).  The CPU restatement's counterpart of refzlib.deflate_calls."""
+    if level == -1:
+        level = 6
+    raw = deflate_cont(data, level, calls, strategy, dictionary or b"")
+    if wbits < 0:
+        return raw
+    if wbits > 15:
+        xfl = 2 if level == 9 else 4 if (strategy >= 2 or level < 2) else 0
+        return bytes([31, 139, 8, 0, 0, 0, 0, 0, xfl, 3]) + raw + crc32(data).to_bytes(4, "little") + (len(data) & 0xFFFFFFFF).to_bytes(4, "little")
+    hdr = (8 + ((wbits - 8) << 4)) << 8
+    lf = 0 if (strategy >= 2 or level < 2) else 1 if level < 6 else 2 if level == 6 else 3
+    hdr |= lf << 6
+    use_dict = dictionary is not None and len(dictionary) >= 0 and dictionary is not None
+    if dictionary is not None:
+        hdr |= 0x20
+    hdr += 31 - hdr % 31
+    head = bytes([hdr >> 8, hdr & 255])
+    if dictionary is not None:
+        head += adler32(dictionary).to_bytes(4, "big")
+    return head + raw + adler32(data).to_bytes(4, "big")

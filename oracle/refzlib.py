@@ -279,7 +279,7 @@ def inflate_zlib(data: bytes, outcap: int):
     return rc, out
 
 
-def deflate_calls(data: bytes, level: int, calls=(), wbits: int = -15, strategy: int = 0, dictionary: bytes = None) -> bytes:
+def deflate_calls(data: bytes, level: int, calls=(), wbits: int = -15, strategy: int = 0, dictionary: bytes = None, params=None) -> bytes:
     """ONE stream of the reference driven call by call: for (upto, flush) in calls, deflate() is handed data[fed:upto] with that flush
     value (Z_NO_FLUSH slices the input, Z_SYNC_FLUSH / Z_FULL_FLUSH / Z_PARTIAL_FLUSH flush); a last call hands over the rest with
     Z_FINISH.  calls == () is what compress2() does (qcsrc/compress.c:22-58).  Output space is never short."""
@@ -295,7 +295,12 @@ def deflate_calls(data: bytes, level: int, calls=(), wbits: int = -15, strategy:
     inb = C.create_string_buffer(data, max(len(data), 1))
     s.next_out = C.addressof(out); s.avail_out = cap
     fed = 0
-    for upto, flush in list(calls) + [(len(data), Z_FINISH)]:
+    L.deflateParams.argtypes = [C.POINTER(ZStream), C.c_int, C.c_int]
+    for k, (upto, flush) in enumerate(list(calls) + [(len(data), Z_FINISH)]):
+        if params and k in params:  # deflateParams() in front of call k (it may flush through next_out: nothing is pending on next_in)
+            s.next_in = C.addressof(inb) + fed; s.avail_in = 0
+            rc = L.deflateParams(C.byref(s), params[k][0], params[k][1])
+            assert rc in (Z_OK, Z_BUF_ERROR), rc  # (Z_BUF_ERROR: its own Z_PARTIAL_FLUSH right behind another flush; the parameters are set all the same)
         s.next_in = C.addressof(inb) + fed; s.avail_in = upto - fed
         rc = L.deflate(C.byref(s), flush)
         want = Z_STREAM_END if flush == Z_FINISH else Z_OK

@@ -66,7 +66,7 @@ def corpus(kind, seed, nbytes):
     return CP.chunks(kind, seed, (nbytes + 65535) // 65536).tobytes()[:nbytes]
 
 
-LEVELS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "6,9,4").split(",")]
+LEVELS = [int(x) for x in (sys.argv[1] if __name__ == "__main__" and len(sys.argv) > 1 else "6,9,4").split(",")]
 
 
 def main():

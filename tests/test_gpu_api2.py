@@ -218,8 +218,9 @@ def test_copies_are_independent_streams(L):
 
 def test_inflate_sync_skips_a_damaged_chunk(L):
     d = cases.make("text", 180000, 13)
-    z = bytearray(Z.compress2(d, 6)[1])
-    z[700] ^= 0x55  # inside the first chunk
+    # a stream with full-flush points every 64 KiB (plain compress2() writes ONE continuous stream since round 4: nothing to sync to)
+    z = bytearray(Z.deflate_stream(d, 6, [(65536, Z.Z_FULL_FLUSH), (65536, Z.Z_FULL_FLUSH), (len(d) - 131072, Z.Z_FINISH)])[0])
+    z[700] ^= 0x55  # inside the first piece
     s = Z.ZStream()
     assert L.inflateInit_(C.byref(s), b"1.2.3", C.sizeof(Z.ZStream)) == Z.Z_OK
     src = C.create_string_buffer(bytes(z), len(z)); out = C.create_string_buffer(200000)

@@ -93,20 +93,13 @@ def test_host_api_dictionary(golden):
     text = cases.make("text", 5000, 4)
     data = CP.chunks(0, 50, 3).tobytes()[:-321]
     for dictionary, level in ((text[:2000], 6), (CP.chunks(0, 49, 1).tobytes(), 9), (b"hello\0", 1), (text[:300], 0)):
-        d = dictionary[-32506:]
-        room = 65536 - len(d)
-        hdr = bytearray(O.deflate_stream(b"", level)[:2])
-        hdr[1] = (hdr[1] & 0xC0) | 0x20
-        hdr[1] += 31 - ((hdr[0] << 8) + hdr[1]) % 31
-        if level == 0:
-            first = O.deflate_chunk(data[:room], 0, False)
-        else:
-            first = O.deflate_chunk_dict(d, data[:room], level, False)
-        rest = data[room:]
-        nrest = (len(rest) + 65535) // 65536
-        want = bytes(hdr) + O.adler32(dictionary).to_bytes(4, "big") + first + b"".join(
-            O.deflate_chunk(rest[k * 65536:(k + 1) * 65536], level, k == nrest - 1) for k in range(nrest)) + O.adler32(data).to_bytes(4, "big")
         for pieces in ([len(data)], [1000, 70000, len(data) - 71000], [30000, 30000, 30000, len(data) - 90000]):
+            # what the reference writes for these calls: ONE stream behind the dictionary (level 0 cuts its blocks by what each call brings)
+            calls, pos = [], 0
+            for n in pieces[:-1]:
+                pos += n
+                calls.append((pos, Z.Z_NO_FLUSH))
+            want = O.cont_stream(data, level, calls, dictionary=dictionary)
             z, dictid = deflate_with_dict(dictionary, data, level, pieces)
             assert dictid == O.adler32(dictionary)
             assert z == want, (level, len(dictionary), pieces)

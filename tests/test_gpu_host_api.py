@@ -1,6 +1,8 @@
 """The zlib-compatible host library (libzamd_z.so) driven the way /root/reference/qcsrc/example.c drives zlib:
 one-shot compress/uncompress, streaming with tiny buffers, flushes, error returns.  Output bytes are compared with the
 CPU oracle's mode-B stream (= the reference's bytes for the same chunking)."""
+import hashlib
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -59,7 +61,12 @@ def test_compress2_uncompress_roundtrip(level, golden):
     assert rc == 0 and back == cases.HELLO
     big = cases.hello_1mib()
     rc, z = Z.compress2(big, level)
-    assert rc == 0 and z == O.deflate_stream(big, 6 if level == -1 else level)
+    # ONE continuous stream since round 4: the bytes of the reference's compress2() (kat.json: 2071 bytes at levels 6 and 9, 5632 at level 1)
+    assert rc == 0 and z == O.cont_stream(big, level)
+    if level != 0:
+        ref = kat["hello_1mib"][str(6 if level == -1 else level)]
+        assert len(z) == ref["compress2_len"] and hashlib.sha256(z).hexdigest() == ref["compress2_sha256"]
+    assert Z.lib().compressBound(len(big)) == kat["compressBound"]["1048576"] == 1048907  # compress.c:75-79
     rc, back = Z.uncompress(z, len(big))
     assert rc == 0 and back == big
 
@@ -81,18 +88,18 @@ def test_compress2_buffer_too_small_and_uncompress_errors():
 def test_streaming_deflate_tiny_buffers():
     """example.c:169-205 feeds and drains one byte at a time; the stream must not depend on the buffering."""
     data = CP.chunks(CP.KIND_SILESIA, 11, 3).tobytes()[:150000]
-    want = O.deflate_stream(data, 6)
+    want = O.cont_stream(data, 6)
     z, codes, info = Z.deflate_stream(data, 6, [(len(data), Z.Z_FINISH)], in_step=None, out_step=7)
     assert z == want and codes[-1] == Z.Z_STREAM_END
     assert info["total_in"] == len(data) and info["total_out"] == len(want) and info["adler"] == O.adler32(data)
     z, codes, info = Z.deflate_stream(data[:70000], 1, [(70000, Z.Z_FINISH)], in_step=1000, out_step=None)
-    assert z == O.deflate_stream(data[:70000], 1) and info["end_rc"] == Z.Z_OK
+    assert z == O.cont_stream(data[:70000], 1) and info["end_rc"] == Z.Z_OK
     # input that ends exactly on a chunk boundary, fed in slices and finished with an empty call (minizip's zipWriteInFileInZip /
     # zipCloseFileInZip, qcsrc/zip.c:969-1062): the last chunk carries the final bit, as in the one-call stream
     for n in (65536, 131072):
         for lvl in (1, 6):
             z, codes, info = Z.deflate_stream(data[:n], lvl, [(n, Z.Z_NO_FLUSH), (0, Z.Z_FINISH)], in_step=16384, out_step=16384)
-            assert z == O.deflate_stream(data[:n], lvl), (n, lvl)
+            assert z == O.cont_stream(data[:n], lvl), (n, lvl)
     small = cases.HELLO
     z, codes, info = Z.deflate_stream(small, 9, [(len(small), Z.Z_FINISH)], in_step=1, out_step=1)
     assert z == O.deflate_stream(small, 9)
@@ -104,8 +111,8 @@ def test_full_flush_points_become_chunk_boundaries():
     cuts = [3, 70000, 70001, 150000]
     plan = [(3, Z.Z_FULL_FLUSH), (69997, Z.Z_FULL_FLUSH), (1, Z.Z_SYNC_FLUSH), (79999, Z.Z_FULL_FLUSH), (50000, Z.Z_FINISH)]
     z, codes, info = Z.deflate_stream(data, 6, plan)
-    pieces = chunks_of(data, cuts)
-    want = bytes.fromhex("789c") + b"".join(O.deflate_chunk(p, 6, i == len(pieces) - 1) for i, p in enumerate(pieces)) + O.adler32(data).to_bytes(4, "big")
+    # what the reference writes for these calls: Z_FULL_FLUSH forgets the history (deflate.c:817), Z_SYNC_FLUSH keeps it (the window stays)
+    want = O.cont_stream(data, 6, [(3, Z.Z_FULL_FLUSH), (70000, Z.Z_FULL_FLUSH), (70001, Z.Z_SYNC_FLUSH), (150000, Z.Z_FULL_FLUSH)])
     assert z == want
     # and the library reads its own flushed stream back, fed one byte at a time
     rc, back, msg, adler = Z.inflate_stream(z[:5000], 10, in_step=1)  # incomplete prefix: every byte is accepted, then a call
@@ -202,13 +209,12 @@ def test_level0_block_structure():
     for n in (0, 1, 1000, 32505, 32506, 32507, 40000, 65531, 65532, 65535, 65536, 65536 + 32506, 2 * 65536 + 40000):
         data = cases.make("text", n, 3)
         z, codes, info = Z.deflate_stream(data, 0, [(n, Z.Z_FINISH)])
-        assert z == O.deflate_stream(data, 0), n
+        assert z == O.cont_stream(data, 0), n
         if n:
             z2, codes, info = Z.deflate_stream(data, 0, [(n, Z.Z_FULL_FLUSH), (0, Z.Z_FINISH)])
-            nch = (n + 65535) // 65536
-            want = O.deflate_stream(b"", 0)[:2] + b"".join(O.deflate_chunk(data[k * 65536:(k + 1) * 65536], 0, False) for k in range(nch)) + \
-                O.deflate_chunk(b"", 0, True) + O.adler32(data).to_bytes(4, "big")
-            assert z2 == want, n
+            assert z2 == O.cont_stream(data, 0, [(n, Z.Z_FULL_FLUSH)]), n
+            z3, codes, info = Z.deflate_stream(data, 0, [(n, Z.Z_FINISH)], in_step=20000)  # (level 0 cuts its blocks by what each call brings)
+            assert z3 == O.cont_stream(data, 0, [(q, Z.Z_NO_FLUSH) for q in range(20000, n, 20000)]), n
 
 
 def test_host_buffers_in_batches_with_copies_under_the_kernels():

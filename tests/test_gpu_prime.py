@@ -49,7 +49,7 @@ def test_deflate_prime_matches_the_reference():
         z = _primed(L, d, c["level"], c["wbits"], c["prime"], c["mid"], False)
         if len(z) != c["len"] or hashlib.sha256(z).hexdigest()[:16] != c["sha"] or (c["stream"] is not None and z.hex() != c["stream"]):
             bad.append((c["kind"], c["n"], c["level"], c["wbits"], c["prime"], c["mid"], len(z), c["len"]))
-        if c["mid"] is None:  # fed in one piece the library writes the same stream
+        if c["mid"] is None and c["n"] <= 65536:  # fed in one piece the library writes the same stream (one continuous stream since round 4: only when there is no flush point)
             assert _primed(L, d, c["level"], c["wbits"], c["prime"], None, True) == z
     assert not bad, bad[:10]
 

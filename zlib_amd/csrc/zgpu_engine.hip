@@ -614,8 +614,10 @@ struct ContFeed { // one call of deflate_cont
 };
 static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, zgpu_cont_state *cs, const uint32_t *d_carry_in, zgpu_deflate_result *res, hipStream_t st)
 {
-    if (!cfg.slow && (!lz_fastwin_serves(cfg) || cfg.strategy == kHuffmanOnly || cfg.strategy == kRle || !f.h_hist))
-        return fail(e, ZGPU_STREAM_ERROR, "continuous stream at levels 1..3: the levels' own parameters, not Z_HUFFMAN_ONLY / Z_RLE");
+    // levels 1-3 with Z_HUFFMAN_ONLY: no match is ever looked for, no chain ever asked: the walkers' path (every byte a literal) serves it
+    const bool fast_lz = !cfg.slow && cfg.strategy != kHuffmanOnly;
+    if (fast_lz && (!lz_fastwin_serves(cfg) || cfg.strategy == kRle || !f.h_hist))
+        return fail(e, ZGPU_STREAM_ERROR, "continuous stream at levels 1..3: the levels' own parameters, not Z_RLE");
     if (cs->entry < cs->abs0 || cs->entry > cs->abs0 + f.buf_bytes || cs->carry_ntok >= kBlockTokens || cs->bit_count > 7) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: state out of range");
     if ((reinterpret_cast<uintptr_t>(f.d_out) & 3) != 0) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: the output must be 4-byte aligned");
     const uint64_t e0 = cs->entry - cs->abs0, w0 = e0 > kTileStride ? e0 - kTileStride : 0;
@@ -638,13 +640,13 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     int rc = ensure_deflate_ws(e, batch, false, 1);
     if (rc) return rc;
     if ((rc = ensure_cont_ws(e, batch, ntiles))) return rc;
-    if (!cfg.slow) {
+    if (fast_lz) {
         if ((rc = ensure_fast_ws(e, batch))) return rc;
         ZGPU_HIP_CHECK(hipMemcpyAsync(e->cf_prev, f.h_hist, (size_t)kInsWords * 4, hipMemcpyHostToDevice, st)); // (pageable: the copy has read it when the call returns)
     }
     const uint64_t seg_end = ends ? cs->abs0 + f.buf_bytes : ~0ull, sp = ends ? cont_special_pos(seg_end) : ~0ull;
     uint32_t nexcl_dev = 0;
-    if (f.nexcl && cfg.slow) { // (levels 1-3 know which positions are in the chains bit by bit: hist bits)
+    if (f.nexcl && !fast_lz) { // (levels 1-3 know which positions are in the chains bit by bit: hist bits)
         if (f.nexcl > e->ct_excl_cap) { hipFree(e->ct_excl); e->ct_excl = nullptr; e->ct_excl_cap = 0; if ((rc = dev_alloc(e, &e->ct_excl, (size_t)f.nexcl + 64))) return rc; e->ct_excl_cap = f.nexcl + 64; }
         std::vector<uint64_t> off(f.nexcl);
         uint32_t k = 0;
@@ -673,7 +675,7 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
         const uint32_t nb = (uint32_t)(ntiles - t0 < batch ? ntiles - t0 : batch);
         const bool last_batch = t0 + nb >= ntiles;
         g.chunk0 = t0; g.nchunks = nb;
-        if (nb && cfg.slow) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
+        if (nb && !fast_lz) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
         else if (nb && (rc = lz_tiles_fast(e, g, tg, cfg, st))) return rc;
         const uint64_t seg_here = (ends && last_batch) ? seg_end : ~0ull;
         {
@@ -728,7 +730,7 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
         const uint64_t wb_last = w0 + (ntiles - 1) * kTileStride, lim = end - wb_last, h1_last = lim < kTileH1 ? lim : kTileH1;
         cs->entry = cs->abs0 + wb_last + h1_last + k_next;
     }
-    if (!cfg.slow) { // the history's bits for the next feed: the 32512 positions (or all there are) in front of where the parse stands
+    if (fast_lz) { // the history's bits for the next feed: the 32512 positions (or all there are) in front of where the parse stands
         uint32_t x0 = 0, count = 0;
         if (ntiles) {
             const uint64_t wb_last = w0 + (ntiles - 1) * kTileStride, e_buf = cs->entry - cs->abs0, nw0 = e_buf > kTileStride && e_buf - kTileStride > w0 ? e_buf - kTileStride : w0;

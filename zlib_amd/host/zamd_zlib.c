@@ -368,7 +368,7 @@ EXPORT int deflateInit2_(z_streamp strm, int level, int method, int windowBits, 
     s->wrap = wrap; s->level = level; s->strategy = strategy; s->w_bits = windowBits; s->mem_level = memLevel;
     /* one continuous stream at the default geometry; another windowBits / memLevel is served in independent chunks.
      * (levels 1-3: the continuous deflate_fast is served since round 4 as well) */
-    s->cont = !chunks_mode() && windowBits == 15 && memLevel == 8;
+    s->cont = !chunks_mode() && windowBits == 15 && memLevel == 8 && !(strategy == Z_RLE && level >= 1 && level <= 3); /* (deflate_fast with longest_match_fast: served in chunks) */
     if (s->cont) { s->carry = (uint32_t *)calloc((size_t)ZGPU_CONT_CARRY_TOKENS + ZGPU_CONT_HIST_WORDS + 8, 4); if (!s->carry) { state_free(strm); return Z_MEM_ERROR; } }
     return deflateReset(strm);
 }
@@ -441,6 +441,22 @@ EXPORT int deflateParams(z_streamp strm, int level, int strategy)
         const int f_old = s->level == 0 ? 0 : s->level <= 3 ? 1 : 2, f_new = level == 0 ? 0 : level <= 3 ? 1 : 2;
         if (f_old != f_new && strm->total_in != 0) rc = deflate(strm, Z_PARTIAL_FLUSH);
         else if ((level != s->level || strategy != s->strategy) && s->level != 0 && s->fed - s->cs.entry > 1024 && s->status != ST_FINISH) rc = cont_feed(strm, NULL, 0, ZGPU_CONT_MORE);
+        if (level >= 1 && level <= 3 && strategy == Z_RLE) return Z_STREAM_ERROR; /* (not served on a continuous stream) */
+        if (rc == Z_OK && f_old == 1 && f_new == 2) {
+            /* deflate_slow inherits deflate_fast's chains: the positions of the history that are NOT in them, as a list */
+            const uint64_t w0 = s->cs.entry > 32512 ? s->cs.entry - 32512 : 0, base0 = w0 > s->win_abs0 ? w0 : s->win_abs0;
+            s->nexcl = 0;
+            for (uint64_t q = base0 > s->floor_pos ? base0 : s->floor_pos; q < s->cs.entry; q++) {
+                const uint64_t j = q - base0;
+                if (!((s->carry[ZGPU_CONT_CARRY_TOKENS + (j >> 5)] >> (j & 31u)) & 1u) && !excl_add(s, q)) return Z_MEM_ERROR;
+            }
+        } else if (rc == Z_OK && f_old == 2 && f_new == 1) {
+            /* ... and deflate_fast deflate_slow's: every position of the history but the listed ones */
+            const uint64_t w0 = s->cs.entry > 32512 ? s->cs.entry - 32512 : 0, base0 = w0 > s->win_abs0 ? w0 : s->win_abs0;
+            memset(s->carry + ZGPU_CONT_CARRY_TOKENS, 0, (size_t)ZGPU_CONT_HIST_WORDS * 4);
+            for (uint64_t q = base0 > s->floor_pos ? base0 : s->floor_pos; q < s->cs.entry; q++) { const uint64_t j = q - base0; s->carry[ZGPU_CONT_CARRY_TOKENS + (j >> 5)] |= 1u << (j & 31u); }
+            for (uint32_t i = 0; i < s->nexcl; i++) if (s->excl[i] >= base0 && s->excl[i] < s->cs.entry) { const uint64_t j = s->excl[i] - base0; s->carry[ZGPU_CONT_CARRY_TOKENS + (j >> 5)] &= ~(1u << (j & 31u)); }
+        }
         if (f_old != f_new) {
             if (f_new == 0) { s->st_str = s->st_blk = s->fed; s->st_off = s->fed >= 65275u ? ((s->fed - 65275u) / 32768u + 1u) * 32768u : 0; s->cs.entry = s->fed; }
             else if (f_old == 0) { s->cs.entry = s->cs.block_start = s->fed; s->floor_pos = s->fed; memset(s->carry + ZGPU_CONT_CARRY_TOKENS, 0, (size_t)ZGPU_CONT_HIST_WORDS * 4); if (!cont_rewindow(s, s->fed, NULL, 0)) return Z_MEM_ERROR; }
@@ -464,6 +480,9 @@ EXPORT int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_l
     if (strm == Z_NULL || strm->state == Z_NULL || strm->state->kind != KIND_DEFLATE) return Z_STREAM_ERROR;
     struct internal_state *s = strm->state;
     s->tuned = 1; s->tune[0] = (uint32_t)good_length; s->tune[1] = (uint32_t)max_lazy; s->tune[2] = (uint32_t)nice_length; s->tune[3] = (uint32_t)max_chain;
+    /* deflate_fast with parameters of the caller's is served by the lane-per-chunk loop, i.e. in independent chunks: a stream that has not begun goes there
+     * (one that has keeps its parameters' level row: the engine refuses the feed) */
+    if (s->cont && s->level >= 1 && s->level <= 3 && s->fed == 0 && !s->any_block && s->out.len == s->out_pos) { s->cont = 0; }
     return Z_OK;
 }
 /* deflate.c:404-413: bi_valid = bits, bi_buf = value's low bits -- the next block starts behind them.  The chunk streams end at byte boundaries
@@ -477,8 +496,9 @@ EXPORT int deflatePrime(z_streamp strm, int bits, int value)
     if (bits < 0 || bits > 16 || s->in.len != 0 || s->status == ST_FINISH) return Z_STREAM_ERROR;
     if (s->cont) { /* bi_valid = bits, bi_buf = value: whole bytes of them go out with the next output, the rest waits in the unfinished byte */
         if (s->fed != s->cs.entry) return Z_STREAM_ERROR; /* (input that is waiting would have been partly emitted in front of the bits by the reference) */
-        s->cs.bit_count = 0; s->cs.bit_value = 0;
-        return bits == 0 || tail_put(s, (uint32_t)value & ((1u << bits) - 1u), bits) ? Z_OK : Z_MEM_ERROR;
+        /* (the bits wait for the next deflate() call: a stream's header, which that call may still have to write, goes in front of them) */
+        s->dprime = ((uint32_t)bits << 16) | (bits ? (uint32_t)value & ((1u << bits) - 1u) : 0u) | 0x80000000u;
+        return Z_OK;
     }
     s->dprime = bits ? ((uint32_t)bits << 16) | ((uint32_t)value & ((1u << bits) - 1u)) : 0u;
     return Z_OK;
@@ -722,8 +742,13 @@ static int cont_deflate(z_streamp strm, int flush)
     struct internal_state *s = strm->state;
     const uint8_t *src = strm->next_in; const size_t n = strm->avail_in;
     strm->next_in += n; strm->total_in += n; strm->avail_in = 0;
-    static long feed_min = -1;
-    if (feed_min < 0) { const char *v = getenv("ZAMD_FEED_BYTES"); feed_min = v ? strtol(v, NULL, 10) : (16l << 20); if (feed_min < 1024) feed_min = 1024; }
+    if (s->dprime) { /* deflatePrime: bi_valid = bits, bi_buf = value (deflate.c:411-412) */
+        const uint32_t pb = (s->dprime >> 16) & 0x1fu, pv = s->dprime & 0xffffu;
+        s->dprime = 0; s->cs.bit_count = 0; s->cs.bit_value = 0;
+        if (pb && !tail_put(s, pv, (int)pb)) return Z_MEM_ERROR;
+    }
+    long feed_min = 16l << 20;
+    { const char *v = getenv("ZAMD_FEED_BYTES"); if (v && *v) feed_min = strtol(v, NULL, 10); if (feed_min < 1024) feed_min = 1024; }
     if (s->level == 0) {
         if (n) {
             if (!buf_put(&s->win, src, n)) return Z_MEM_ERROR;
