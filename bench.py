@@ -281,7 +281,7 @@ def main():
         traffic, traffic_src, limiter = None, None, None
         try:
             tj = {}
-            for name in ("r02_traffic.json", "r03_traffic.json"):  # (the later round's counters replace the earlier ones for the same kernel and workload)
+            for name in ("r02_traffic.json", "r03_traffic.json", "r04_traffic.json"):  # (the later round's counters replace the earlier ones for the same kernel and workload)
                 fn = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(fn):
                     tj.update(json.load(open(fn)))
@@ -369,7 +369,45 @@ def main():
         dst2 = torch.empty(cap, dtype=torch.uint8, device=dev)
         extra["level1"] = one_level(1, a.steps)
         extra["level9"] = one_level(9, max(1, a.steps // 2))  # (the deepest chains: fewer steps, stated in "steps")
-        del dst2, offs2
+        del offs2
+        # SURVEY.md 8f N1 (round 4): the same input as ONE continuous stream -- what plain compress2() of the reference emits: the window slides through the
+        # whole input, matches cross every 64 KiB boundary, blocks are cut every 16383 tokens from the stream's start.  Next to the headline's independent
+        # chunks: rate, ratio, and the first 256 MiB as a stream of their own against the compiled reference's length and SHA-256 (tests/golden/continuous_kat.json)
+        def continuous(level, steps):
+            import hashlib
+            ccap = eng.L.zgpu_deflate_cont_bound(nbytes) + 64
+            cdst = dst2 if ccap <= cap else torch.empty(ccap, dtype=torch.uint8, device=dev)
+            st = {}
+
+            def f():
+                st["res"] = eng.deflate_device(src.data_ptr(), nbytes, level, cdst.data_ptr(), max(cap, ccap), flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP | gpu.F_CONTINUOUS, stream=stream)
+            d, pr = timed(f, steps, 1)
+            out = {"metric": "GiB/s raw input compressed (deflate level %d), ONE continuous stream" % level, "value": round(nbytes * steps / d / 2**30, 4), "unit": "GiB/s",
+                   "steps": steps, "warmup": 1, "ms_per_step": round(d / steps * 1e3, 3), "compression_ratio": round(nbytes / st["res"].out_bytes, 4),
+                   "stream_bytes": int(st["res"].out_bytes), "roofline": roofline_of(pr, steps, nbytes, st["res"].out_bytes, "deflate-continuous", level)}
+            try:
+                rows = [r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "continuous_kat.json")))["rows"]
+                        if r["corpus"] == kind and r["level"] == level and r["sync_at"] is None and r["n"] == (256 << 20) and r["n"] <= nbytes]
+            except (OSError, ValueError, KeyError):
+                rows = []
+            if rows and a.workload == "silesia-mix":
+                r = rows[0]
+                res = eng.deflate_device(src.data_ptr(), r["n"], level, cdst.data_ptr(), max(cap, ccap), flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP | gpu.F_CONTINUOUS, stream=stream)
+                z = cdst[: res.out_bytes].cpu().numpy().tobytes()
+                if len(z) != r["len"] or hashlib.sha256(z).hexdigest() != r["sha256"]:
+                    sys.exit("continuous stream of the first %d MiB at level %d differs from the reference's compress2() (%d bytes, fixture %d)" % (r["n"] >> 20, level, len(z), r["len"]))
+                out["first_256_mib_equal_to_reference_compress2"] = True
+            if not a.no_cpu_baseline:
+                from oracle import refzlib
+                if refzlib.available():  # one stream is one core's work: the reference's own loop cannot be cut into threads
+                    sample = src[: min(nbytes, 48 << 20)].cpu().numpy().tobytes()
+                    t0 = time.perf_counter(); zr = refzlib.compress2(sample, level); dt = time.perf_counter() - t0
+                    out["cpu_baseline"] = {"value": round(len(sample) / dt / 2**30, 4), "unit": "GiB/s", "cores": 1, "kind": "reference",
+                                           "sample": "compress2() of the first %d MiB, level %d, %.1f s, ratio %.3f" % (len(sample) >> 20, level, dt, len(sample) / len(zr)), "cpu_model": cpu_model()}
+            return out
+        extra["continuous"] = continuous(a.level, max(1, a.steps // 2))
+        extra["continuous_level1"] = continuous(1, 1)
+        del dst2
         # the zlib-API path hands over host buffers: H2D of the input, the same kernels, D2H of the stream (SURVEY.md 8d "end-to-end")
         import ctypes as C
         import numpy as np

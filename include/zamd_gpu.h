@@ -105,7 +105,8 @@ typedef struct {
  * wrapper) and the only exchange is this gather.  The reference has no distributed path.  RCCL is dlopen()ed by the first call here.
  *   rank 0: zgpu_comm_unique_id(id); the 128 bytes reach the other ranks by any channel; every rank: zgpu_comm_create(device, world, rank, id, &c);
  *   per stream, every rank: zgpu_deflate_gather_sizes (an all-gather of three u64 per rank: rank 0 learns the exact size of the stream),
- *   then zgpu_deflate_gather (one send per peer; on rank 0 one receive per peer at its offset, all in one group). */
+ *   then zgpu_deflate_gather (one send per peer; on rank 0 one receive per peer at its offset, all in one group).  Both calls return when the
+ *   stream has drained on the calling rank: d_body may be reused then.  The gathered stream's header is the default strategy's (FLEVEL from the level). */
 typedef struct zgpu_comm zgpu_comm;
 #define ZGPU_COMM_ID_BYTES 128
 int zgpu_comm_unique_id(void *id128);

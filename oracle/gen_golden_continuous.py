@@ -33,6 +33,12 @@ def main():
                     z = R.deflate_calls(data, level, calls, wbits=15)
                     rows.append({"corpus": kind, "n": n, "level": level, "sync_at": sync_at, "len": len(z), "sha256": hashlib.sha256(z).hexdigest(), "head": z[:32].hex()})
                     print(kind, n, level, sync_at, len(z), flush=True)
+    # the bench's check (bench.py extra.continuous): the first 256 MiB of the headline workload as one stream
+    big = corpus(0, 256 << 20)
+    for level in (6, 1):
+        z = R.deflate_calls(big, level, (), wbits=15)
+        rows.append({"corpus": 0, "n": len(big), "level": level, "sync_at": None, "len": len(z), "sha256": hashlib.sha256(z).hexdigest(), "head": z[:32].hex()})
+        print(0, len(big), level, None, len(z), flush=True)
     out = {"reference": R.version(), "seeds": {str(k): v for k, v in SEEDS.items()}, "rows": rows}
     with open(os.path.join(ROOT, "tests", "golden", "continuous_kat.json"), "w") as f:
         json.dump(out, f, indent=0)

@@ -50,6 +50,28 @@ def ref_primed(L, data, level, wbits, prime, mid=None):
     return b"".join(parts)
 
 
+def ref_primed_one_stream(L, data, level, wbits, prime, mid=None):
+    """ONE stream of the reference driven as tests/test_gpu_prime.py drives the product's z_stream API: deflatePrime, then 65536 bytes and Z_FULL_FLUSH per call
+    (Z_FINISH on the last), `mid`: a second deflatePrime behind the first call.  What libzamd_z.so writes since round 4 (one continuous stream)."""
+    s = R.ZStream()
+    assert L.deflateInit2_(C.byref(s), level, 8, wbits, 8, 0, b"1.2.3", C.sizeof(R.ZStream)) == 0
+    assert L.deflatePrime(C.byref(s), prime[0], prime[1]) == 0
+    cap = len(data) + (len(data) >> 7) + 512
+    out = C.create_string_buffer(cap)
+    inb = C.create_string_buffer(data, max(len(data), 1))
+    s.next_out = C.addressof(out); s.avail_out = cap
+    nchunks = max(1, (len(data) + R.CHUNK - 1) // R.CHUNK)
+    for k in range(nchunks):
+        s.next_in = C.addressof(inb) + k * R.CHUNK; s.avail_in = min(R.CHUNK, len(data) - k * R.CHUNK)
+        last = k + 1 == nchunks
+        assert L.deflate(C.byref(s), R.Z_FINISH if last else R.Z_FULL_FLUSH) == (1 if last else 0)
+        if k == 0 and mid is not None and not last:
+            assert L.deflatePrime(C.byref(s), mid[0], mid[1]) == 0
+    z = out.raw[: s.total_out]
+    L.deflateEnd(C.byref(s))
+    return z
+
+
 def main():
     L = R.lib()
     L.deflatePrime.argtypes = [C.POINTER(R.ZStream), C.c_int, C.c_int]
@@ -61,8 +83,10 @@ def main():
                 wbits = -15 if (i + level) % 3 else 15
                 mid = PRIMES[(i + 3) % len(PRIMES)] if (n > R.CHUNK and i % 2 == 0) else None
                 z = ref_primed(L, d, level, wbits, prime, mid)
+                za = ref_primed_one_stream(L, d, level, wbits, prime, mid)
                 out.append(dict(kind=kind, n=n, seed=seed, level=level, wbits=wbits, prime=list(prime), mid=list(mid) if mid else None, len=len(z),
-                                sha=hashlib.sha256(z).hexdigest()[:16], stream=z.hex() if len(z) <= 200 else None))
+                                sha=hashlib.sha256(z).hexdigest()[:16], stream=z.hex() if len(z) <= 200 else None,
+                                api_len=len(za), api_sha=hashlib.sha256(za).hexdigest()[:16]))
     with open(os.path.join(ROOT, "tests", "golden", "prime_kat.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("wrote prime_kat.json: %d cases" % len(out))

@@ -47,8 +47,10 @@ def test_deflate_prime_matches_the_reference():
     for c in KAT:
         d = cases.make(c["kind"], c["n"], c["seed"])
         z = _primed(L, d, c["level"], c["wbits"], c["prime"], c["mid"], False)
-        if len(z) != c["len"] or hashlib.sha256(z).hexdigest()[:16] != c["sha"] or (c["stream"] is not None and z.hex() != c["stream"]):
-            bad.append((c["kind"], c["n"], c["level"], c["wbits"], c["prime"], c["mid"], len(z), c["len"]))
+        # (api_*: the reference as ONE stream driven by the same calls -- what the z_stream API writes since round 4; len / sha: a fresh stream per chunk,
+        #  what the engine's chunk entry points write; the two coincide for a single chunk)
+        if len(z) != c["api_len"] or hashlib.sha256(z).hexdigest()[:16] != c["api_sha"] or (c["stream"] is not None and c["n"] <= 65536 and z.hex() != c["stream"]):
+            bad.append((c["kind"], c["n"], c["level"], c["wbits"], c["prime"], c["mid"], len(z), c["api_len"]))
         if c["mid"] is None and c["n"] <= 65536:  # fed in one piece the library writes the same stream (one continuous stream since round 4: only when there is no flush point)
             assert _primed(L, d, c["level"], c["wbits"], c["prime"], None, True) == z
     assert not bad, bad[:10]

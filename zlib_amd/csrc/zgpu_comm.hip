@@ -163,6 +163,7 @@ int zgpu_deflate_gather(zgpu_comm *c, const void *d_body, const uint64_t *table,
     if (mine && !d_body) return comm_fail(ZGPU_STREAM_ERROR, "null body");
     if (c->rank != 0) {
         if (mine) { ZNCCL(g_rccl.GroupStart()); ZNCCL(g_rccl.Send(d_body, mine, ncclUint8, 0, c->comm, st)); ZNCCL(g_rccl.GroupEnd()); }
+        ZHIP(hipStreamSynchronize(st)); // (the call returns when the body has been sent, on every rank: d_body may be reused or freed then -- ADVICE round 3)
         return ZGPU_OK;
     }
     if (total > out_cap) return comm_fail(ZGPU_BUF_ERROR, "output capacity too small");

@@ -1289,7 +1289,7 @@ EXPORT int inflate(z_streamp strm, int flush)
     if (s->pending_err && drained) return in_bad(strm, s->pending_msg);
     if (s->mode == IN_DONE && drained) { s->status = ST_DONE; return Z_STREAM_END; }
     if (flush == Z_FINISH) return Z_BUF_ERROR; /* not all input, or not enough room (inflate.c:1150-1151) */
-    if (in0 == 0 && out0 == strm->avail_out) return Z_BUF_ERROR;
+    if (in0 == strm->avail_in && out0 == strm->avail_out) return Z_BUF_ERROR; /* no progress was possible (inflate.c:1150-1151): nothing absorbed, nothing delivered -- a caller that loops on Z_OK must not spin */
     return Z_OK;
 }
 
