@@ -135,6 +135,23 @@ def test_large_foreign_stream_in_slices_is_delivered_as_it_arrives(L):
     assert half_out is not None and half_out >= len(data) // 4, "with half of the input in, only %d of %d bytes had come out" % (half_out, len(data))
 
 
+def test_stream_taken_up_at_a_bit_offset_when_the_pieces_decline(L):
+    """a stream without flush points is taken up again inside a byte; when the decode in pieces says "not this way" there for a harmless
+    reason (no scratch room, too many repairs of the chain, the resolve flag -- forced here with ZGPU_SPEC_DECLINE_AT_BIT) the one-workgroup decoder's result on
+    the shifted copy stands: the stream must come out whole, not end in Z_DATA_ERROR."""
+    import os
+    data = CP.chunks(CP.KIND_SILESIA, 31, 96).tobytes()[: 96 * 65536 - 4321]
+    z = zlib.compress(data, 6)
+    trailing = b"behind the stream"
+    os.environ["ZGPU_SPEC_DECLINE_AT_BIT"] = "1"
+    try:
+        for in_step, out_step in ((700000, 1 << 20), (400000, 300000)):
+            rc, got, left, trace = _inflate_loop(L, z, 15, in_step, out_step, len(data), trailing)
+            assert rc == Z.Z_STREAM_END and got == data and left == len(trailing), (in_step, rc, len(got))
+    finally:
+        del os.environ["ZGPU_SPEC_DECLINE_AT_BIT"]
+
+
 def test_gzread_two_members_larger_than_the_file_buffer_small_reads(L, tmp_path):
     """Two gzip members, each larger than the reader's 1 MiB file buffer, one of them sync-flushed by the system zlib, read 3000 bytes at a time."""
     a = CP.chunks(CP.KIND_SILESIA, 40, 40).tobytes()
