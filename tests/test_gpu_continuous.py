@@ -90,13 +90,14 @@ def test_engine_one_shot_against_the_restatement(eng):
     for strategy, levels in ((1, (1, 6)), (2, (6,)), (3, (6, 9)), (4, (2, 6))):
         for level in levels:
             assert eng.deflate_host(d[: 1 << 20], level, flags=F, strategy=strategy) == O.deflate_cont(d[: 1 << 20], level, strategy=strategy), (strategy, level)
-    for bt in ("1", "3", "64"):
+    for bt, pipe in (("1", "0"), ("3", "2"), ("7", "2"), ("64", "0")):  # (ZGPU_CONT_PIPE=2: a batch's blocks are made on a second stream under the next batch's walkers)
         os.environ["ZGPU_CONT_BATCH_TILES"] = bt
+        os.environ["ZGPU_CONT_PIPE"] = pipe
         try:
-            for level in (1, 6):
-                assert eng.deflate_host(d, level, flags=F) == O.deflate_cont(d, level), (bt, level)
+            for level in (1, 6, 9):
+                assert eng.deflate_host(d, level, flags=F) == O.deflate_cont(d, level), (bt, pipe, level)
         finally:
-            del os.environ["ZGPU_CONT_BATCH_TILES"]
+            del os.environ["ZGPU_CONT_BATCH_TILES"], os.environ["ZGPU_CONT_PIPE"]
     for name, d2 in (("a", b"a" * (1 << 20)), ("ab", b"ab" * (1 << 19)), ("zeros", bytes(200000))):  # walkers that never meet: the exits' serial path
         for level in (1, 4, 9):
             assert eng.deflate_host(d2, level, flags=F) == O.deflate_cont(d2, level), (name, level)

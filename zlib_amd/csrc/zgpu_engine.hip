@@ -34,11 +34,13 @@ uint32_t *lz_sorted_fault_word(void *workspace);
 void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, uint16_t *comp, uint16_t *gentry, hipStream_t st,
                      void *prof, int exact_sort);
 uint32_t chain_groups(uint32_t ntiles);
+void launch_lz_tiles_parse(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof);
 void launch_sort_tiles(const ChunkGeom &g, void *workspace, ChunkMeta *meta, hipStream_t st, void *prof, int exact_sort, const uint16_t **S_out, const uint32_t **ir_out);
-void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st);
+void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, uint32_t ngrid,
+                             hipStream_t st);
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st);
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
-                      uint32_t *count, hipStream_t st);
+                      uint32_t *count, uint32_t *list, hipStream_t st);
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
                         const uint32_t *low, hipStream_t st);
 void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st);
@@ -104,7 +106,8 @@ struct zgpu_engine {
     // ... levels 1-3: the rounds of fastwin_tile_kernel
     uint32_t cf_tiles = 0;
     uint16_t *cf_exit_a = nullptr, *cf_exit_b = nullptr; uint32_t *cf_ins0 = nullptr, *cf_ins1 = nullptr, *cf_prev = nullptr, *cf_prev2 = nullptr, *cf_hist = nullptr, *cf_count = nullptr;
-    uint8_t *cf_cur = nullptr, *cf_act_a = nullptr, *cf_act_b = nullptr, *cf_changed = nullptr;
+    uint8_t *cf_cur = nullptr, *cf_act_a = nullptr, *cf_act_b = nullptr, *cf_changed = nullptr; uint32_t *cf_list_a = nullptr, *cf_list_b = nullptr;
+    hipStream_t ct_stream = nullptr; hipEvent_t ct_ev_a[2] = {nullptr, nullptr}, ct_ev_b[2] = {nullptr, nullptr}; // levels 4-9: a batch's blocks are made on a second stream under the next batch's walkers
     uint64_t cf_rounds = 0, cf_tile_parses = 0; // (diagnostic: rounds and tile parses since the engine was made)
     // profiling
     bool prof = false;
@@ -548,6 +551,7 @@ static int ensure_fast_ws(zgpu_engine *e, uint32_t batch_tiles)
     }
     if (batch_tiles > e->cf_tiles) {
         hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed);
+        hipFree(e->cf_list_a); hipFree(e->cf_list_b); e->cf_list_a = e->cf_list_b = nullptr;
         e->cf_exit_a = e->cf_exit_b = nullptr; e->cf_ins0 = e->cf_ins1 = nullptr; e->cf_cur = e->cf_act_a = e->cf_act_b = e->cf_changed = nullptr; e->cf_tiles = 0;
         if ((rc = dev_alloc(e, &e->cf_exit_a, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_exit_b, (size_t)batch_tiles))) return rc;
@@ -557,6 +561,8 @@ static int ensure_fast_ws(zgpu_engine *e, uint32_t batch_tiles)
         if ((rc = dev_alloc(e, &e->cf_act_a, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_act_b, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_changed, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_list_a, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_list_b, (size_t)batch_tiles))) return rc;
         e->cf_tiles = batch_tiles;
     }
     return ZGPU_OK;
@@ -570,34 +576,43 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
     StageTimer t(e, st, ZGPU_STAGE_MATCH);
     launch_fast_init(e->cf_cur, e->cf_act_a, e->cf_exit_a, nb, st);
     uint8_t *act = e->cf_act_a, *act_next = e->cf_act_b;
+    uint32_t *list = nullptr, *list_next = e->cf_list_a, ngrid = nb;
     for (uint32_t round = 0;; round++) {
         FastTiles ft{};
         ft.exit_cur = e->cf_exit_a; ft.exit_new = e->cf_exit_b; ft.ins0 = ft.ins0w = e->cf_ins0; ft.ins1 = ft.ins1w = e->cf_ins1; ft.cur = e->cf_cur; ft.active = act; ft.changed = e->cf_changed;
-        ft.prev_ins = e->cf_prev; ft.round = round; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
+        ft.prev_ins = e->cf_prev; ft.round = round; ft.list = list; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
         static uint32_t *dbg = nullptr;
         const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
         if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
         ft.dbg = trace && nb <= 65536 ? dbg : nullptr;
         if (ft.dbg) hipMemsetAsync(dbg, 0xff, (size_t)nb * 32, st);
-        launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, st);
+        launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, ngrid, st);
         if (ft.dbg) {
             std::vector<uint32_t> h((size_t)nb * 8);
             hipMemcpyAsync(h.data(), dbg, (size_t)nb * 32, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
             for (uint32_t c = 0; c < nb && c < 40; c++) if (h[c * 8] != 0xffffffffu)
                 fprintf(stderr, "   tile %u: %u words differ (%u .. %u), exit %u (was %u), entry %u, %u tokens\n", c, h[c * 8 + 1], h[c * 8 + 2], h[c * 8 + 3], h[c * 8 + 4], h[c * 8 + 5], h[c * 8 + 6], h[c * 8 + 7]);
         }
-        launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, st);
+        launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, list_next, st);
         uint32_t active = 0;
         ZGPU_HIP_CHECK(hipMemcpyAsync(&active, e->cf_count, 4, hipMemcpyDeviceToHost, st));
         ZGPU_HIP_CHECK(hipStreamSynchronize(st));
         e->cf_rounds++; e->cf_tile_parses += round == 0 ? nb : 0;
         static int force = -1; // ZGPU_FAST_FORCE_ROUNDS=n (debug): every tile is parsed again in each of the first n rounds
         if (force < 0) { const char *v = getenv("ZGPU_FAST_FORCE_ROUNDS"); force = v ? atoi(v) : 0; }
-        if ((int)round < force) { ZGPU_HIP_CHECK(hipMemsetAsync(act_next + 1, 1, nb - 1, st)); active = nb - 1; }
+        if ((int)round < force && nb > 1) { // (all of them again: the list is 1 .. nb - 1)
+            std::vector<uint32_t> all(nb - 1);
+            for (uint32_t i = 1; i < nb; i++) all[i - 1] = i;
+            ZGPU_HIP_CHECK(hipMemsetAsync(act_next + 1, 1, nb - 1, st));
+            ZGPU_HIP_CHECK(hipMemcpyAsync(list_next, all.data(), (size_t)(nb - 1) * 4, hipMemcpyHostToDevice, st));
+            ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+            active = nb - 1;
+        }
         if (getenv("ZGPU_FAST_TRACE")) fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again\n", round, active, nb);
         if (active == 0) break;
         e->cf_tile_parses += active;
         uint8_t *x = act; act = act_next; act_next = x;
+        list = list_next; list_next = list == e->cf_list_a ? e->cf_list_b : e->cf_list_a; ngrid = active;
     }
     launch_fast_finish(e->cf_cur, e->cf_exit_a, e->cf_ins0, e->cf_ins1, nb, tg.entry + g.chunk0 + nb, e->cf_prev, e->cf_prev2, g.chunk0 == 0 ? e->cf_hist : nullptr, st);
     return ZGPU_OK;
@@ -636,10 +651,25 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
             if (fit < batch_max) batch_max = (uint32_t)fit;
         }
     }
+    // levels 4-9, more than one batch: two sets of per-batch buffers, half a batch each -- batch k's tokens, blocks and bits are made on a second stream
+    // while batch k + 1 is sorted and walked on the first (ZGPU_CONT_PIPE=0: one after the other, for A/B runs)
+    int pipe_env = 0; // 1: feeds of 2048 tiles and more, 2: whatever the size of the feed (tests).  Off by default: measured at 4 GiB, level 6, 242 ms against 238 --
+                      // two walker workgroups fill a CU's LDS, so the other stream's kernels run beside the sort only, and both are bound by the same memory system
+    { const char *v = getenv("ZGPU_CONT_PIPE"); if (v && *v) pipe_env = atoi(v); }
+    const bool pipe = !fast_lz && (pipe_env == 2 ? ntiles >= 2 : pipe_env == 1 && ntiles >= 2048);
+    if (pipe) { // at least four batches, so that all but the first one's walkers and the last one's blocks have something running beside them
+        const uint64_t want = (ntiles + 3) / 4;
+        if (batch_max >= 2048) batch_max /= 2;
+        if (want >= 1024 && want < batch_max) batch_max = (uint32_t)want;
+    }
     const uint32_t batch = (uint32_t)(ntiles < batch_max ? (ntiles ? ntiles : 1) : batch_max);
-    int rc = ensure_deflate_ws(e, batch, false, 1);
+    int rc = ensure_deflate_ws(e, pipe ? 2 * batch + 1 : batch, false, 1);
     if (rc) return rc;
-    if ((rc = ensure_cont_ws(e, batch, ntiles))) return rc;
+    if ((rc = ensure_cont_ws(e, pipe ? 2 * batch : batch, ntiles))) return rc;
+    if (pipe && !e->ct_stream) {
+        ZGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->ct_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) { ZGPU_HIP_CHECK(hipEventCreateWithFlags(&e->ct_ev_a[i], hipEventDisableTiming)); ZGPU_HIP_CHECK(hipEventCreateWithFlags(&e->ct_ev_b[i], hipEventDisableTiming)); }
+    }
     if (fast_lz) {
         if ((rc = ensure_fast_ws(e, batch))) return rc;
         ZGPU_HIP_CHECK(hipMemcpyAsync(e->cf_prev, f.h_hist, (size_t)kInsWords * 4, hipMemcpyHostToDevice, st)); // (pageable: the copy has read it when the call returns)
@@ -662,7 +692,9 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     { const uint16_t z = 0; ZGPU_HIP_CHECK(hipMemcpyAsync(e->ct_entry, &z, 2, hipMemcpyHostToDevice, st)); }
     const bool check_sort = !e->exact_sort;
     uint32_t sort_fault = 0;
-    if (check_sort) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(e->par_ws), 0, 4, st));
+    const size_t ws_half = (lz_sorted_workspace_bytes(batch) + 255) & ~(size_t)255;
+    uint8_t *const ws_set[2] = {static_cast<uint8_t *>(e->par_ws), static_cast<uint8_t *>(e->par_ws) + (pipe ? ws_half : 0)};
+    if (check_sort) { ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(ws_set[0]), 0, 4, st)); if (pipe) ZGPU_HIP_CHECK(hipMemsetAsync(lz_sorted_fault_word(ws_set[1]), 0, 4, st)); }
 
     ChunkGeom g{};
     g.in = f.d_buf; g.in_bytes = f.buf_bytes; g.chunk_size = kChunkMax; g.final_chunk = ~0ull; g.block_tokens = kBlockTokens; g.slot_stride = kSlotStride;
@@ -671,29 +703,41 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     tg.abs0 = cs->abs0; tg.e0 = e0; tg.end = end; tg.nil_pos = (sp != ~0ull && sp >= cs->abs0 && sp < seg_end) ? sp - cs->abs0 : ~0ull; tg.abs0_nil = 1;
     tg.exits = e->ct_exits; tg.entry = e->ct_entry;
     const uint64_t out_cap4 = f.out_cap & ~3ull;
-    for (uint64_t t0 = 0; t0 == 0 || t0 < ntiles; t0 += batch) { // (a feed without tiles still closes the block that is filling)
+    hipStream_t sb = pipe ? e->ct_stream : st; // where a batch's blocks are made
+    if (pipe) { ZGPU_HIP_CHECK(hipEventRecord(e->ct_ev_a[0], st)); ZGPU_HIP_CHECK(hipStreamWaitEvent(sb, e->ct_ev_a[0], 0)); } // (the second stream starts behind what the caller has queued: the input, the state)
+    uint64_t kbatch = 0;
+    for (uint64_t t0 = 0; t0 == 0 || t0 < ntiles; t0 += batch, kbatch++) { // (a feed without tiles still closes the block that is filling)
         const uint32_t nb = (uint32_t)(ntiles - t0 < batch ? ntiles - t0 : batch);
         const bool last_batch = t0 + nb >= ntiles;
+        const int set = pipe ? (int)(kbatch & 1) : 0;
+        uint32_t *const tokens = e->tokens + (size_t)set * batch * kChunkMax;
+        ChunkMeta *const tmeta = e->meta + (size_t)set * batch;
+        tg.exits = e->ct_exits + (size_t)set * batch * kTileExitStride;
         g.chunk0 = t0; g.nchunks = nb;
-        if (nb && !fast_lz) launch_lz_tiles(g, tg, cfg, e->par_ws, e->tokens, e->meta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
+        if (pipe && kbatch >= 2) ZGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ct_ev_b[set], 0)); // this set's buffers: the batch before last is done with them
+        if (nb && !fast_lz) launch_lz_tiles(g, tg, cfg, ws_set[set], tokens, tmeta, e->ct_comp, e->ct_gentry, st, e, e->exact_sort);
         else if (nb && (rc = lz_tiles_fast(e, g, tg, cfg, st))) return rc;
+        if (pipe) { ZGPU_HIP_CHECK(hipEventRecord(e->ct_ev_a[set], st)); ZGPU_HIP_CHECK(hipStreamWaitEvent(sb, e->ct_ev_a[set], 0)); }
+        if (nb && !fast_lz) launch_lz_tiles_parse(g, tg, cfg, ws_set[set], tokens, tmeta, sb, e);
         const uint64_t seg_here = (ends && last_batch) ? seg_end : ~0ull;
         {
-            StageTimer t(e, st, ZGPU_STAGE_PARSE);
-            launch_cont_tokens(g, tg, e->tokens, e->meta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH && seg_here != ~0ull, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, cfg.slow != 0, st);
+            StageTimer t(e, sb, ZGPU_STAGE_PARSE);
+            launch_cont_tokens(g, tg, tokens, tmeta, e->ct_st, e->ct_tokoff, t0 == 0 ? d_carry_in : e->ct_carry, e->ct_T, e->ct_blk, seg_here, f.mode == ZGPU_CONT_FINISH && seg_here != ~0ull, seg_here != ~0ull ? sp : ~0ull, e->ct_nblk, cfg.slow != 0, sb);
         }
         {
-            StageTimer t(e, st, ZGPU_STAGE_HUFFMAN);
-            launch_huffman_cont(g, e->ct_T, e->ct_nblk, e->ct_blk, e->ct_st, e->ct_slots, st, cfg.strategy == kFixed);
+            StageTimer t(e, sb, ZGPU_STAGE_HUFFMAN);
+            launch_huffman_cont(g, e->ct_T, e->ct_nblk, e->ct_blk, e->ct_st, e->ct_slots, sb, cfg.strategy == kFixed);
         }
         {
-            StageTimer t(e, st, ZGPU_STAGE_STITCH);
-            launch_cont_stitch(e->ct_blk, e->ct_st, e->ct_pos, e->ct_slots, kSlotStride, f.d_buf, cs->abs0, f.d_out, out_cap4, e->ct_nblk, e->ct_T, e->ct_carry, seg_here, st);
+            StageTimer t(e, sb, ZGPU_STAGE_STITCH);
+            launch_cont_stitch(e->ct_blk, e->ct_st, e->ct_pos, e->ct_slots, kSlotStride, f.d_buf, cs->abs0, f.d_out, out_cap4, e->ct_nblk, e->ct_T, e->ct_carry, seg_here, sb);
         }
+        if (pipe) ZGPU_HIP_CHECK(hipEventRecord(e->ct_ev_b[set], sb));
         const hipError_t he = hipGetLastError();
         if (he != hipSuccess) return zgpu::fail_hip(e, he, "kernel launch", __FILE__, __LINE__);
         if (ntiles == 0) break;
     }
+    if (pipe) { ZGPU_HIP_CHECK(hipEventRecord(e->ct_ev_b[0], sb)); ZGPU_HIP_CHECK(hipStreamWaitEvent(st, e->ct_ev_b[0], 0)); } // everything the second stream has made lies in front of what follows
     // checksums of the bytes this feed brought
     uint32_t adler = 1, crc = 0;
     if (f.check_from < f.buf_bytes) {
@@ -720,9 +764,12 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     uint16_t k_next = 0;
     ZGPU_HIP_CHECK(hipMemcpyAsync(&hs, e->ct_st, sizeof hs, hipMemcpyDeviceToHost, st));
     if (ntiles) ZGPU_HIP_CHECK(hipMemcpyAsync(&k_next, e->ct_entry + ntiles, 2, hipMemcpyDeviceToHost, st));
-    if (check_sort) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault, lz_sorted_fault_word(e->par_ws), 4, hipMemcpyDeviceToHost, st));
+    uint32_t sort_fault2 = 0;
+    if (check_sort) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault, lz_sorted_fault_word(ws_set[0]), 4, hipMemcpyDeviceToHost, st));
+    if (check_sort && pipe) ZGPU_HIP_CHECK(hipMemcpyAsync(&sort_fault2, lz_sorted_fault_word(ws_set[1]), 4, hipMemcpyDeviceToHost, st));
     ZGPU_HIP_CHECK(hipStreamSynchronize(st));
     collect_spans(e);
+    sort_fault |= sort_fault2;
     if (sort_fault) { e->exact_sort = 1; return deflate_cont(e, f, cfg, cs, d_carry_in, res, st); } // (nothing of cs or of the incoming carry has been touched yet)
     if (hs.overflow) return fail(e, ZGPU_BUF_ERROR, "output capacity too small");
     // where the stream stands now
@@ -814,11 +861,13 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipFree(e->ct_exits); hipFree(e->ct_entry); hipFree(e->ct_comp); hipFree(e->ct_gentry); hipFree(e->ct_tokoff); hipFree(e->ct_T); hipFree(e->ct_carry); hipFree(e->ct_carry_in); hipFree(e->ct_blk);
     hipFree(e->ct_pos); hipFree(e->ct_slots); hipFree(e->ct_st); hipFree(e->ct_ckmeta); hipFree(e->ct_excl);
     hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_prev); hipFree(e->cf_prev2); hipFree(e->cf_hist); hipFree(e->cf_count);
-    hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed);
+    hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed); hipFree(e->cf_list_a); hipFree(e->cf_list_b);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);
     for (auto ev : e->done_ev) hipEventDestroy(ev);
+    if (e->ct_stream) hipStreamDestroy(e->ct_stream);
+    for (int i = 0; i < 2; i++) { if (e->ct_ev_a[i]) hipEventDestroy(e->ct_ev_a[i]); if (e->ct_ev_b[i]) hipEventDestroy(e->ct_ev_b[i]); }
     if (e->d2h_stream) hipStreamDestroy(e->d2h_stream);
     if (e->pin_tot) hipHostFree(e->pin_tot);
     hipStreamDestroy(e->copy_stream);

@@ -406,8 +406,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
     constexpr int NW = NICE / 8;
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    if (ft.round != 0 && !ft.active[c]) return;
+    const uint32_t c = ft.list ? ft.list[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
     const bool warm = ft.round == 0 && c != 0;
     uint64_t wb; uint32_t n, h0, h1, nent;
     tile_span(g, tg, c, wb, n, h0, h1, nent);
@@ -743,14 +742,14 @@ __global__ void __launch_bounds__(256) fast_init_kernel(uint8_t *cur, uint8_t *a
 }
 // behind a round: the tiles that were parsed make their new results current; a tile is parsed again when its predecessor's results have changed
 __global__ void __launch_bounds__(256) fast_flip_kernel(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new,
-                                                        uint32_t n, uint32_t round, uint32_t *count)
+                                                        uint32_t n, uint32_t round, uint32_t *count, uint32_t *list)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (round == 0 || active[i]) { cur[i] ^= 1; exit_cur[i] = exit_new[i]; }
     const bool nx = i >= 1 && (round == 0 || (active[i - 1] && changed[i - 1]));
     active_next[i] = nx ? 1 : 0;
-    if (nx) atomicAdd(count, 1u);
+    if (nx) list[atomicAdd(count, 1u)] = i; // (any order: the tiles of a round do not depend on each other)
 }
 // behind the last round of a batch: the entry of the tile behind the batch, and the batch's last bits as the next batch's history
 __global__ void __launch_bounds__(256) fast_finish_kernel(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after,
@@ -782,10 +781,10 @@ __global__ void __launch_bounds__(256) fast_hist_kernel(const uint32_t *before, 
 }
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st) { hipLaunchKernelGGL(fast_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, exit_cur, n); }
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
-                      uint32_t *count, hipStream_t st)
+                      uint32_t *count, uint32_t *list, hipStream_t st)
 {
     hipMemsetAsync(count, 0, 4, st);
-    hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count);
+    hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count, list);
 }
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
                         const uint32_t *low, hipStream_t st)
@@ -797,8 +796,10 @@ void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0,
     hipLaunchKernelGGL(fast_hist_kernel, dim3((kInsWords + 255) / 256), dim3(256), 0, st, before, last, x0, count, out);
 }
 
-void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, hipStream_t st)
+void launch_lz_fastwin_tiles(const ChunkGeom &g0, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, uint32_t ngrid,
+                             hipStream_t st)
 {
+    ChunkGeom g = g0; // (g.nchunks stays the batch's: the launch is over `ngrid` of its tiles)
     static bool opt_in = false;
     if (!opt_in) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
@@ -806,9 +807,9 @@ void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastT
         hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
         opt_in = true;
     }
-    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
-    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
-    else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32>), dim3(g.nchunks), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
 }
 
 } // namespace zgpu

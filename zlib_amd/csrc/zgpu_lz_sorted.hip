@@ -1474,6 +1474,21 @@ void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void 
     prof_span_end(prof, st, ZGPU_STAGE_MATCH, ev);
     prof_span_begin(prof, st, &ev);
     launch_chain(tg.exits, g.nchunks, comp, gentry, tg.entry + g.chunk0, st);
+    prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
+    (void)tokens;
+}
+// ... and the tiles' tokens from their true entries: a launch of its own, so that it can run on another stream under the next batch's walkers (it is all
+// latency -- a window at a time, one wave threading the path -- and they are bound by the vector units: what the chunk path gets by fusing the two)
+void launch_lz_tiles_parse(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void *workspace, uint32_t *tokens, ChunkMeta *meta, hipStream_t st, void *prof)
+{
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    const size_t nch = g.nchunks;
+    uint16_t *rk = reinterpret_cast<uint16_t *>(w + 256 + ((nch * kSStride * 2 + 255) & ~(size_t)255));
+    uint32_t *heads = reinterpret_cast<uint32_t *>(rk + nch * kChunkMax);
+    uint2 *recs = reinterpret_cast<uint2 *>(heads + nch * kHeadStride);
+    uint32_t *gm = reinterpret_cast<uint32_t *>(recs), *gs = gm + nch * kChunkMax;
+    hipEvent_t ev{};
+    prof_span_begin(prof, st, &ev);
     launch_parse_tile(g, cfg, gm, gs, tokens, meta, tg, st);
     prof_span_end(prof, st, ZGPU_STAGE_PARSE, ev);
 }
