@@ -33,8 +33,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--level", type=int, default=6)
-    ap.add_argument("--gib", type=float, default=4.0, help="GiB of input per GPU")
-    ap.add_argument("--workload", default="silesia-mix", choices=["silesia-mix", "log-text"])
+    ap.add_argument("--gib", type=float, default=None, help="GiB of input per GPU (default: 4 at N = 1, 8 at N > 1)")
+    ap.add_argument("--workload", default=None, choices=["silesia-mix", "log-text"],
+                    help="default: silesia-mix at N = 1 (BASELINE.json configs[1]), log-text at N > 1 (configs[4]: 8 GiB of it per rank)")
     ap.add_argument("--lz", default="auto", choices=["auto", "serial", "parallel", "sorted", "walk", "fast", "fastwin"])
     ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
@@ -113,7 +114,7 @@ def cpu_baseline(sample, level, threads, op="deflate"):
                 what, len(sample) >> 20, dt, "" if op == "inflate" else ", ratio %.3f" % (len(sample) / out_bytes))}
 
 
-def check_sampled_chunks(torch, dst, offs, nchunks, rank_chunk0, level, workload, nsample=64):
+def check_sampled_chunks(torch, dst, offs, nchunks, rank_chunk0, level, workload, nsample=64, final=True, fail=sys.exit):
     """The claim "bit-exact" checked in the run that makes it: `nsample` of the chunks the committed fixture samples (tests/golden/corpus_*.json: the
     REFERENCE's output length and SHA-256 per chunk at levels 1 / 6 / 9, generated by oracle/gen_golden.py from the compiled reference) are cut out of the
     stream just produced and compared.  Returns the number checked, or exits.  (None: no fixture for this level or workload.)"""
@@ -123,8 +124,11 @@ def check_sampled_chunks(torch, dst, offs, nchunks, rank_chunk0, level, workload
     path = os.path.join(ROOT, "tests", "golden", name)
     if col is None or not os.path.exists(path):
         return None
-    rows = [r for r in json.load(open(path))["rows"] if rank_chunk0 <= r[0] < rank_chunk0 + nchunks - 1]  # (the last chunk carries BFINAL: not the fixture's variant)
+    g = json.load(open(path))
+    rows = [r for r in g["rows"] if rank_chunk0 <= r[0] < rank_chunk0 + nchunks - 1]
     rows = rows[:: max(1, len(rows) // nsample)][:nsample]
+    if final:  # this range ends the stream: its last chunk carries BFINAL, the variant the fixture's `last_rows` hold
+        rows += [r for r in g.get("last_rows", []) if r[0] == rank_chunk0 + nchunks - 1]
     if not rows:
         return None
     idx = torch.tensor([r[0] - rank_chunk0 for r in rows], dtype=torch.int64, device=offs.device)
@@ -133,7 +137,7 @@ def check_sampled_chunks(torch, dst, offs, nchunks, rank_chunk0, level, workload
     for r, a, b in zip(rows, lo, hi):
         seg = dst[a:b].cpu().numpy().tobytes()
         if [len(seg), hashlib.sha256(seg).hexdigest()[:16]] != r[col:col + 2]:
-            sys.exit("chunk %d at level %d differs from the reference's output (%d bytes, fixture %d)" % (r[0], level, len(seg), r[col]))
+            return fail("chunk %d at level %d differs from the reference's output (%d bytes, fixture %d)" % (r[0], level, len(seg), r[col]))
     return len(rows)
 
 
@@ -150,6 +154,12 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
+    # N = 1: the configuration BASELINE.json's metric is quoted on (4 GiB silesia-mix); N > 1: its multi-GPU configuration (SURVEY.md 8d config 5:
+    # log-text, 8 GiB per rank, rank r compresses chunks [131072 r, 131072 (r + 1)) of the corpus tests/golden/corpus_logtext.json samples)
+    if a.workload is None:
+        a.workload = "silesia-mix" if world == 1 else "log-text"
+    if a.gib is None:
+        a.gib = 4.0 if world == 1 else 8.0
     # ZAMD_BENCH_SHARE_GPU=1: a REHEARSAL of the N > 1 flow on a box with one GPU (every rank on GPU 0, gloo for the process group, and
     # ZAMD_RCCL_LIB naming the test double of tests/tools/fake_rccl.cpp).  Its JSON line says so; it is no measurement.
     share = os.environ.get("ZAMD_BENCH_SHARE_GPU") == "1"
@@ -256,10 +266,24 @@ def main():
         return dt, prof
 
     dt, prof = timed(step, a.steps, a.warmup)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank checks ITS sampled chunks against the reference's hashes (the last rank's last chunk carries BFINAL: the fixture's last_rows) and
+        # times its own steps (device events of its stages); rank 0 reports all of them and the job fails when any rank's bytes differ
+        own_ms = sum(v[0] for v in prof.values() if v[1]) / a.steps
+        bad = []
+        nchk = check_sampled_chunks(torch, dst, offs, nchunks, rank * nchunks, a.level, a.workload, final=rank == world - 1, fail=bad.append) if a.op == "deflate" else None
+        mine = torch.tensor([dt, own_ms, -1.0 if bad else float(nchk or 0), float(state["res"].out_bytes)], dtype=torch.float64, device=cdev)
+        table = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(table, mine)
+        table = [t.cpu().tolist() for t in table]
+        if bad:
+            print("rank %d: %s" % (rank, bad[0]), file=sys.stderr, flush=True)
+        if any(t[2] < 0 for t in table):
+            sys.exit("rank(s) %s produced bytes that differ from the reference's" % [r for r, t in enumerate(table) if t[2] < 0])
+        dt = max(t[0] for t in table)
+        per_rank = {"wall_ms_per_step": [round(t[0] / a.steps * 1e3, 2) for t in table], "device_ms_per_step": [round(t[1], 2) for t in table],
+                    "chunks_checked_against_reference_hashes": [int(t[2]) for t in table], "body_bytes": [int(t[3]) for t in table]}
 
     if a.op == "inflate":
         ok = bool(torch.equal(src, src2))
@@ -311,8 +335,9 @@ def main():
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
                 "gathered_bytes": int(state.get("gathered", res.out_bytes)), "gather": comm_note,
                 **({"rehearsal": "ZAMD_BENCH_SHARE_GPU: all ranks on one GPU, no measurement"} if share else {}),
-                "chunks_checked_against_reference_hashes": (check_sampled_chunks(torch, dst, offs, nchunks, rank * nchunks, a.level, a.workload)
-                                                            if a.op == "deflate" else None)},
+                "chunks_checked_against_reference_hashes": (sum(per_rank["chunks_checked_against_reference_hashes"]) if per_rank else
+                                                            check_sampled_chunks(torch, dst, offs, nchunks, 0, a.level, a.workload) if a.op == "deflate" else None),
+                **({"per_rank": per_rank} if per_rank else {})},
             "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),
         }
     # ---- the other configurations of BASELINE.json on the same input, outside the timed region of the headline (N = 1 only):

@@ -31,11 +31,11 @@ def test_4gib_level6_against_reference_hashes_and_roundtrip():
         assert res.nchunks == nchunks
         o = offs.cpu().numpy()
         assert o[0] == 2 and o[-1] + 4 == res.out_bytes
-        # every sampled chunk; the stream's very last chunk carries BFINAL instead of the flush marker the fixture was made with
-        for row in g["rows"]:
+        # every sampled chunk; the stream's very last chunk carries BFINAL instead of the flush marker: the fixture's `last_rows` hold that variant
+        last = [r for r in g["last_rows"] if r[0] == nchunks - 1]
+        assert len(last) == 1
+        for row in [r for r in g["rows"] if r[0] != nchunks - 1] + last:
             k = row[0]
-            if k == nchunks - 1:
-                continue
             seg = dst[int(o[k]): int(o[k + 1])].cpu().numpy().tobytes()
             assert [len(seg), hashlib.sha256(seg).hexdigest()[:16]] == row[col: col + 2], (level, k)
         # trailer = Adler-32 of the whole input, recomputed on the device by a different code path
@@ -47,6 +47,37 @@ def test_4gib_level6_against_reference_hashes_and_roundtrip():
         assert r.out_bytes == nbytes and r.adler32 == trailer
         assert torch.equal(src, back)
         del back
+    eng.close()
+
+
+def test_reference_inflate_accepts_the_device_stream():
+    """Config 4: the stock inflate must accept the stream.  The device's level-6 stream of the first 256 MiB of the workload through the compiled
+    reference's uncompress() (oracle/_ref/libzref.so, prebuilt in the development container) and through the interpreter's zlib."""
+    import zlib
+    import torch
+    import zlib_amd
+    from zlib_amd import gpu
+    from oracle import refzlib as R
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_silesia.json")))
+    nchunks = 4096
+    nbytes = nchunks * 65536
+    eng = zlib_amd.Engine(0)
+    dev = torch.device("cuda", 0)
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    eng.corpus_fill_device(g["kind"], g["seed"], 0, nchunks, src.data_ptr())
+    cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
+    dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    res = eng.deflate_device(src.data_ptr(), nbytes, 6, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP)
+    z = dst[: res.out_bytes].cpu().numpy().tobytes()
+    data = src.cpu().numpy().tobytes()
+    row = [r for r in g["last_rows"] if r[0] == nchunks - 1][0]
+    assert hashlib.sha256(z[-4 - row[4]:-4]).hexdigest()[:16] == row[5]  # the BFINAL chunk: the reference's bytes
+    assert zlib.decompress(z) == data
+    if R.available():
+        rc, out = R.uncompress(z, nbytes)
+        assert rc == 0 and out == data
+    else:
+        pytest.skip("oracle/_ref/libzref.so is not in this checkout: checked with the interpreter's zlib only")
     eng.close()
 
 
@@ -76,10 +107,12 @@ def test_8gib_logtext_rank_share_against_reference_hashes(rank):
     assert o[0] == 0 and o[-1] == res.out_bytes
     rows = [r for r in g["rows"] if lo <= r[0] < hi]
     assert len(rows) >= 32
+    if rank == world - 1:  # the chunk that carries BFINAL: `last_rows` hold the reference's output for it
+        last = [r for r in g["last_rows"] if r[0] == hi - 1]
+        assert len(last) == 1
+        rows = [r for r in rows if r[0] != hi - 1] + last
     for row in rows:
         k = row[0] - lo
-        if row[0] == g["total_chunks"] - 1:
-            continue  # (carries BFINAL here, the flush marker in the fixture)
         seg = dst[int(o[k]): int(o[k + 1])].cpu().numpy().tobytes()
         assert [len(seg), hashlib.sha256(seg).hexdigest()[:16]] == row[4:6], (rank, row[0])
     assert res.adler32 == eng.adler32_device(src.data_ptr(), nbytes)

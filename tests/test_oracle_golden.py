@@ -79,6 +79,12 @@ def test_corpus_sample(golden, fname, stride):
         for j, lvl in enumerate((1, 6, 9)):
             o = O.deflate_chunk(data, lvl, False)
             assert [len(o), h16(o)] == row[2 + 2 * j: 4 + 2 * j], (row[0], lvl)
+    for row in g["last_rows"]:  # the chunks a run ends on, with BFINAL (oracle/gen_golden_last.py)
+        data = CP.chunk(g["kind"], row[0])
+        assert h16(data) == row[1]
+        for j, lvl in enumerate((1, 6, 9)):
+            o = O.deflate_chunk(data, lvl, True)
+            assert [len(o), h16(o)] == row[2 + 2 * j: 4 + 2 * j], (row[0], lvl, "last")
 
 
 def test_inflate_cases(golden):

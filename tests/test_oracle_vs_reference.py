@@ -36,6 +36,24 @@ def test_stream_matches_reference_mode_b():
         assert rc == 0 and out == data
 
 
+def test_reference_inflate_accepts_the_256_mib_prefix_stream():
+    """BASELINE.json config 4 asks that the stock inflate accepts the chunked stream.  The first 256 MiB of the 4 GiB workload as the mode-B stream
+    (the restatement's bytes: the device's are compared with them chunk by chunk in tests/test_gpu_fullsize.py, and handed to the same reference call
+    in tests/test_gpu_fullsize.py::test_reference_inflate_accepts_the_device_stream) through the compiled reference's uncompress()."""
+    import hashlib
+    import json
+    n = 256 << 20
+    data = CP.chunks(CP.KIND_SILESIA, 0, n // 65536)
+    z = O.deflate_stream(data, 6)
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "corpus_silesia.json")))
+    rc, out = R.uncompress(z, n)
+    assert rc == 0 and len(out) == n and hashlib.sha256(out).digest() == hashlib.sha256(data.tobytes()).digest()
+    assert int.from_bytes(z[-4:], "big") == R.adler32(out)
+    # the last chunk of this prefix is one of the fixture's last_rows (BFINAL set): the stream ends with exactly those bytes
+    row = [r for r in g["last_rows"] if r[0] == n // 65536 - 1][0]
+    assert hashlib.sha256(z[-4 - row[4]:-4]).hexdigest()[:16] == row[5]
+
+
 def test_mode_a_equals_mode_b_except_position0():
     """in one zlib stream flushed with Z_FULL_FLUSH every 64 KiB, chunk 0 is F(.., pos0=0)
     and every later chunk is F(.., pos0_matchable=1)."""

@@ -416,6 +416,189 @@ __global__ void __launch_bounds__(kS3Threads) sort3_kernel(ChunkGeom g, uint16_t
     if (bad) atomicOr(fault, 1u);
 }
 
+// ------------------------------------------------------------------------------------------------- K1c (round 4)
+// sort3_kernel with the ranks kept where they are made.  sort3 writes every position's rank to HBM in pass A (rk[]), reads it back and rewrites it as the
+// index in pass C0 (which also reads the input a second time for the hashes), and reads the index twice more in pass C1: 43 GB of the sort's 77 GB per 4 GiB,
+// for a scratch array that exists only because a lane's passes work on different positions.  Here a lane keeps ITS positions through all passes -- the 64 of
+// pass A's turns (turn T = wave + 16 j, step u: position 512 T + 64 u + lane) -- one register each: hash, then hash | rank << 16, then the position's `ir` word
+// (index | rank << 16), from which pass C1 scatters.  The input is read once, rk[] is not touched, what goes to HBM is S and ir.  Same token round, same
+// self-check, same results (tests/test_gpu_deflate.py runs every golden vector through it; ZGPU_SORT=3 is the older kernel).
+__global__ void __launch_bounds__(kS3Threads) sort4_kernel(ChunkGeom g, uint16_t *__restrict__ S_all, uint32_t *__restrict__ heads_all, uint32_t *__restrict__ fault,
+                                                           uint32_t *__restrict__ ir_all, ChunkMeta *__restrict__ meta)
+{
+    __shared__ uint32_t ad1[kS3Waves];
+    __shared__ uint64_t ad2[kS3Waves];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[kHashSize / 2];
+    __shared__ uint32_t wave_tot[kS3Waves];
+    __shared__ uint32_t token;
+    __shared__ __attribute__((aligned(8))) uint32_t heads[kChunkMax / 32];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t lo; uint32_t n;
+    chunk_span(g, c, lo, n);
+    const uint8_t *src = g.in + lo;
+    uint16_t *S = S_all + (size_t)c * kSStride + kSPad;
+    uint32_t *hd = heads_all + (size_t)c * kHeadStride, *ir = ir_all + (size_t)c * kChunkMax;
+    if (threadIdx.x < kSPad) S[-(int)kSPad + (int)threadIdx.x] = 0;
+    uint32_t last_of_half0 = 0;
+    const uint32_t npos = n >= 3 ? n - 2 : 0, nturns = (npos + kS3TurnPos - 1) / kS3TurnPos;
+    const uint32_t nout = g.nexcl ? excl_lower(g, lo + npos) - excl_lower(g, lo) : 0u, nin = npos - nout;
+    const uint32_t cnt_a = lds_off(cnt), tok_a = lds_off(&token);
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(cnt);
+        for (uint32_t i = tid; i < kHashSize * 2 / 16; i += kS3Threads) z[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) token = 0;
+        for (uint32_t i = tid; i < kChunkMax / 32; i += kS3Threads) heads[i] = 0;
+    }
+    __syncthreads();
+    auto bytes3 = [&](uint32_t p) -> uint32_t {
+        if (p + 4 <= n) return reinterpret_cast<const U32u *>(src + p)->v & 0xffffffu;
+        return (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+    };
+    auto hash_of = [](uint32_t v) { return hash3(v & 255u, (v >> 8) & 255u, v >> 16); };
+    constexpr uint32_t kTurnsPerWave = kChunkMax / kS3TurnPos / kS3Waves; // 8
+    constexpr uint32_t kNone32 = 0xffffffffu;
+    uint32_t pk[kTurnsPerWave][kS3TurnSteps]; // this lane's 64 positions: hash -> hash | rank << 16 -> index | rank << 16; kNone32: no position, or not in the chains
+
+    // ---- pass A: rank(p) ----
+    {
+        uint32_t s1 = 0, s2 = 0;
+        auto preload = [&](uint32_t T, uint32_t (&h)[kS3TurnSteps]) {
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                const uint32_t p = T * kS3TurnPos + 64 * u + lane, v = p < npos ? bytes3(p) : 0u;
+                h[u] = p < npos ? hash_of(v) : kNone32;
+                if (nout && p < npos && excl_has(g, lo + p)) h[u] = kNone32;
+                s1 += v & 255u; s2 += (n - p) * (v & 255u);
+            }
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < kTurnsPerWave; j++)
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) pk[j][u] = kNone32;
+        if (wave < nturns) preload(wave, pk[0]);
+#pragma unroll
+        for (uint32_t j = 0; j < kTurnsPerWave; j++) {
+            const uint32_t T = wave + j * kS3Waves;
+            __builtin_amdgcn_sched_barrier(0);
+            if (T < nturns) { // (uniform)
+                uint32_t aa[kS3TurnSteps], vv[kS3TurnSteps], old[kS3TurnSteps];
+#pragma unroll
+                for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                    const bool ok = pk[j][u] != kNone32;
+                    aa[u] = cnt_a + (ok ? (pk[j][u] >> 1) << 2 : 0);
+                    vv[u] = ok ? 1u << ((pk[j][u] & 1u) << 4) : 0;
+                }
+                while (lds_ld32(tok_a) != T) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (uint32_t u = 0; u < kS3TurnSteps; u++) old[u] = lds_add_rtn32_nowait(aa[u], vv[u]);
+                lds_st32(tok_a, T + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
+#pragma unroll
+                for (uint32_t u = 0; u < kS3TurnSteps; u++)
+                    if (pk[j][u] != kNone32) pk[j][u] |= ((old[u] >> ((pk[j][u] & 1u) << 4)) & 0xffffu) << 16;
+                if (j + 1 < kTurnsPerWave && T + kS3Waves < nturns) preload(T + kS3Waves, pk[j + 1 < kTurnsPerWave ? j + 1 : j]);
+            }
+        }
+        uint64_t t2 = s2;
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o); t2 += __shfl_down(t2, o); }
+        if (lane == 0) { ad1[wave] = s1; ad2[wave] = t2; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t a = 1, b = n;
+        for (uint32_t w = 0; w < kS3Waves; w++) { a += ad1[w]; b += ad2[w] % 65521u; }
+        for (uint32_t p = npos; p < n; p++) { a += src[p]; b += (uint64_t)(n - p) * src[p]; }
+        ChunkMeta &mc = meta[chunk_of(g, c)];
+        mc.adler_a = (uint32_t)(a % 65521u); mc.adler_b = (uint32_t)(b % 65521u); mc.in_bytes = n;
+    }
+
+    // ---- pass B: exclusive scan of the 32768 counts -> bucket starts (in place) ----
+    {
+        constexpr uint32_t per = kHashSize / kS3Threads, nv = per * 2 / 16;
+        uint4 *c4 = reinterpret_cast<uint4 *>(cnt) + tid * nv;
+        uint32_t v[nv * 4], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < nv; i++) { const uint4 q = c4[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+#pragma unroll
+        for (uint32_t i = 0; i < nv * 4; i++) sum += (v[i] & 0xffffu) + (v[i] >> 16);
+        uint32_t x = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+        if (lane == 63) wave_tot[wave] = x;
+        __syncthreads();
+        uint32_t basev = x - sum;
+        for (uint32_t w = 0; w < wave; w++) basev += wave_tot[w];
+#pragma unroll
+        for (uint32_t i = 0; i < nv * 4; i++) {
+            const uint32_t c0 = v[i] & 0xffffu, c1 = v[i] >> 16;
+            v[i] = (basev & 0xffffu) | ((basev + c0) << 16);
+            basev += c0 + c1;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < nv; i++) c4[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    __syncthreads();
+
+    // ---- pass C0: idx(p) = start(hash) + rank: the position's ir word, written and kept; a bit per bucket head ----
+    const uint16_t *start = reinterpret_cast<const uint16_t *>(cnt);
+#pragma unroll
+    for (uint32_t j = 0; j < kTurnsPerWave; j++) {
+        const uint32_t T = wave + j * kS3Waves;
+        __builtin_amdgcn_sched_barrier(0); // one turn's eight at a time: all 64 in flight do not fit the registers
+        if (T < nturns) {
+#pragma unroll
+            for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                const uint32_t p = T * kS3TurnPos + 64 * u + lane;
+                if (pk[j][u] != kNone32) {
+                    const uint32_t r = pk[j][u] >> 16, id = (uint32_t)start[pk[j][u] & 0x7fffu] + r;
+                    pk[j][u] = id | (r << 16);
+                    ir[p] = pk[j][u];
+                    if (r == 0) atomicOr(&heads[id >> 5], 1u << (id & 31u));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < kChunkMax / 32; i += kS3Threads) hd[i] = heads[i];
+    reinterpret_cast<uint16_t *>(hd + kHeadWords)[tid] = (uint16_t)heads_below(reinterpret_cast<const unsigned long long *>(heads)[tid], tid, wave_tot);
+
+    // ---- pass C1: the scatter through LDS, half of S at a time, and the self-check (see sort3_kernel) ----
+    uint16_t *stage = reinterpret_cast<uint16_t *>(cnt);
+    bool bad = false;
+    for (uint32_t half = 0; half < 2 && half * 32768u < nin; half++) {
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < kTurnsPerWave; j++) {
+            const uint32_t T = wave + j * kS3Waves;
+            __builtin_amdgcn_sched_barrier(0);
+            if (T < nturns) {
+#pragma unroll
+                for (uint32_t u = 0; u < kS3TurnSteps; u++) {
+                    asm volatile("" : "+v"(pk[j][u])); // (nothing derived from it is kept across the two halves: there are no registers for that)
+                    if (pk[j][u] != kNone32 && ((pk[j][u] >> 15) & 1u) == half) stage[pk[j][u] & 32767u] = (uint16_t)(T * kS3TurnPos + 64 * u + lane);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t cntH = nin - half * 32768u < 32768u ? nin - half * 32768u : 32768u;
+        for (uint32_t v = tid; v * 8 < cntH; v += kS3Threads) {
+            const uint4 q = reinterpret_cast<const uint4 *>(stage)[v];
+            *reinterpret_cast<uint4 *>(S + half * 32768u + v * 8) = q;
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const uint32_t hb = (heads[(half * 32768u + v * 8) >> 5] >> ((v * 8) & 31u)) & 0xffu;
+            uint32_t prev = v ? stage[v * 8 - 1] : (half ? last_of_half0 : 0);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t cur = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                if (v * 8 + k < cntH && !((hb >> k) & 1u) && prev >= cur) bad = true;
+                prev = cur;
+            }
+        }
+        if (half == 0 && nin > 32768u) { __syncthreads(); last_of_half0 = stage[32767]; }
+    }
+    if (bad) atomicOr(fault, 1u);
+}
+
 // ------------------------------------------------------------------------------------------------- K2'
 __device__ inline uint32_t lds_ld32u(uint32_t a) // 4 bytes at any LDS byte offset: aligned ds_read2_b32 + v_alignbyte
 {
@@ -1354,13 +1537,14 @@ bool launch_lz_sorted(const ChunkGeom &g, LevelCfg cfg, void *workspace, uint32_
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
     static int sort_env = -1;
-    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 4; } // 4: sort4_kernel, 3: sort3_kernel, 1: the ballot-ranked sort
     if (exact_sort || sort_env == 1) {
         hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
         hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
     }
     else {
-        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        if (sort_env == 3) hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        else hipLaunchKernelGGL(sort4_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, heads, fault, ir, meta);
         adler_done = true;
         if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st); // zgpu_debug_inject_sort_fault(): exercise the engine's fallback without a real fault
     }
@@ -1432,12 +1616,13 @@ void launch_sort_tiles(const ChunkGeom &g, void *workspace, ChunkMeta *meta, hip
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
     static int sort_env = -1;
-    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 4; } // 4: sort4_kernel, 3: sort3_kernel, 1: the ballot-ranked sort
     if (exact_sort || sort_env == 1) {
         hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
         hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
     } else {
-        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        if (sort_env == 3) hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        else hipLaunchKernelGGL(sort4_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, heads, fault, ir, meta);
         if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st);
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
@@ -1458,12 +1643,13 @@ void launch_lz_tiles(const ChunkGeom &g, const TileGeom &tg, LevelCfg cfg, void 
     hipEvent_t ev{};
     prof_span_begin(prof, st, &ev);
     static int sort_env = -1;
-    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 3; }
+    if (sort_env < 0) { const char *e = getenv("ZGPU_SORT"); sort_env = e ? atoi(e) : 4; } // 4: sort4_kernel, 3: sort3_kernel, 1: the ballot-ranked sort
     if (exact_sort || sort_env == 1) {
         hipLaunchKernelGGL(sort_kernel, dim3(g.nchunks), dim3(kSortThreads), 0, st, g, S, rk, heads, ir);
         hipLaunchKernelGGL(heads_below_kernel, dim3(g.nchunks), dim3(1024), 0, st, heads);
     } else {
-        hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        if (sort_env == 3) hipLaunchKernelGGL(sort3_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, rk, heads, fault, ir, meta);
+        else hipLaunchKernelGGL(sort4_kernel, dim3(g.nchunks), dim3(kS3Threads), 0, st, g, S, heads, fault, ir, meta);
         if (g_inject_sort_fault.exchange(0)) hipMemsetAsync(fault, 1, 4, st);
     }
     prof_span_end(prof, st, ZGPU_STAGE_CHAIN, ev);
