@@ -6,7 +6,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/variants; OBJ=$ROOT/build/variants/obj_$NAME
 mkdir -p $OBJ
-for f in zgpu_engine zgpu_lz_serial zgpu_lz_parallel zgpu_lz_sorted zgpu_lz_fastwin zgpu_lz_parse zgpu_huffman zgpu_stitch zgpu_inflate zgpu_comm; do
+for f in zgpu_engine zgpu_lz_serial zgpu_lz_parallel zgpu_lz_sorted zgpu_lz_fastwin zgpu_lz_parse zgpu_cont zgpu_huffman zgpu_stitch zgpu_inflate zgpu_comm; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -Wno-unused-result "$@" -c $ROOT/zlib_amd/csrc/$f.hip -o $OBJ/$f.o &
 done
 wait

@@ -23,8 +23,8 @@ f(out, 1)
 e.deflate_device(src.data_ptr(), n * 65536, lvl, dst.data_ptr(), cap, flags=gpu.F_FINAL)
 torch.cuda.synchronize()
 f(out, 0)
-names = ["pass: starts", "bodies", "folds in bodies", "setup", "pass: drain", "pass: parse", "pass: blocks"]
-tot = sum(int(out[i]) for i in range(7))
+names = ["pass: starts", "bodies (rest)", "folds in bodies", "bodies: byte reads", "pass: drain", "pass: parse", "pass: blocks", "bodies: take-over wait"]
+tot = sum(int(out[i]) for i in range(8))
 for i, nm in enumerate(names):
     print("%-16s %9.0f cycles per wave and chunk  %5.1f%%" % (nm, int(out[i]) / n / 8, 100.0 * int(out[i]) / tot))
 print("total %.0f cycles per wave and chunk" % (tot / n / 8))

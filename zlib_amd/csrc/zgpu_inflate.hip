@@ -53,6 +53,9 @@ constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 256;
 #ifndef ZGPU_INF_RING
 #define ZGPU_INF_RING 32768
 #endif
+#ifndef ZGPU_INF_RING_DEFAULT_KB
+#define ZGPU_INF_RING_DEFAULT_KB 8 // the ring of chunks decoded straight into place (zgpu_inflate_device); ZGPU_INF_RING_KB at run time
+#endif
 constexpr uint32_t kOutRing = ZGPU_INF_RING, kOutHalf = kOutRing / 2; // the last 32 KiB of output live in LDS (the farthest a distance reaches)
 
 // Decoding table entries of the literal/length and distance codes carry everything the symbol loop needs:
@@ -447,14 +450,21 @@ struct SpecArgs {
     uint16_t *tails;      // per segment: the ring when it ended, oldest symbol first = the last 32 KiB of the segment's output
     SpecEnd *ends;
 };
-template <bool SPEC>
+// RING: bytes of output the workgroup keeps in LDS.  32768 is the farthest a distance reaches: every match copies from the ring.  A smaller ring
+// (chunks placed directly at their offset of the destination only) lets more segments share a CU; a match that reaches farther back than RING reads its
+// source from the destination itself, where every byte older than the ring has been flushed: the lanes that hold such matches ask for their first 32 bytes
+// when their half of the token ring is handed over, all at once, and the copy takes them from registers when its turn comes.
+template <bool SPEC, uint32_t RING = ZGPU_INF_RING>
 __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
                                                         uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
                                                         uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
                                                         const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t stream_mode, SpecArgs sp)
 {
     typedef typename std::conditional<SPEC, uint16_t, uint8_t>::type ring_t;
-    typedef InflateLdsT<ring_t> Lds;
+    typedef InflateLdsT<ring_t, RING> Lds;
+    constexpr uint32_t kOutRing = RING, kOutHalf = RING / 2; // (this kernel's ring, not the file's default)
+    constexpr bool FAR = RING < 32768;
+    static_assert(!(SPEC && FAR) && RING >= 4096 && (RING & (RING - 1)) == 0, "ring size");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     Lds &L = *reinterpret_cast<Lds *>(lds_raw);
     const uint32_t c = blockIdx.x, lane = threadIdx.x & 63u;
@@ -811,6 +821,7 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
             for (uint32_t i = lane; i < nbytes; i += 64) d[i] = src_r[i];
         }
         flushed = upto;
+        if (FAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // what has been flushed IS in memory: matches read it back from there
         INF_T(3);
     };
     uint32_t reader_err = kMsgNone;
@@ -835,6 +846,29 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
                 const uint64_t bad = __ballot(far || over);
                 if (bad) err = ((__ballot(far) >> (uint32_t)__builtin_ctzll(bad)) & 1) ? kMsgTooFar : kMsgOutput;
                 uint64_t todo = bad ? 0ull : __ballot(ol != 0);
+                // FAR: matches whose source is no longer in the ring (the ring holds the RING bytes in front of a token when its turn comes)
+                uint64_t farm = 0, pfm = 0;
+                uint32_t p0, p1, p2, p3, p4, p5, p6, p7; // (written by the loads below when they arrive, read after the wait in front of their first use: nothing else may touch them in between)
+                if (FAR) {
+                    const bool isfar = k2 == 2 && (tw >> 11) >= kOutRing;
+                    farm = todo & __ballot(isfar);
+                    if (farm && dst_room >= 32) {
+                        // the source ends below flushed - RING / 2 + 516: flushed, and in memory (flush_to waits for its stores).  32 bytes at once when
+                        // the match is that short and the 32 bytes lie inside what is flushed (and inside the destination: one that is too small gets no
+                        // reads past its end).  Every lane loads -- the others the destination's first bytes -- so that the registers have one writer;
+                        // sc0 sc1: from memory, not from a line this CU's cache took in when only a part of it had been flushed.
+                        const uint32_t s0 = offv - (tw >> 11) - 1;
+                        const bool rdy = isfar && len <= 32 && s0 + 32 <= flushed && (uint64_t)s0 + 32 <= dst_room;
+                        pfm = farm & __ballot(rdy);
+                        const uint8_t *ps = dst + (rdy ? s0 : 0u);
+                        if (pfm) // (uniform; every such run waits for these loads when the first of its lanes' matches is copied)
+                        asm volatile("global_load_dword %0, %8, off sc0 sc1\n\tglobal_load_dword %1, %8, off offset:4 sc0 sc1\n\t"
+                                     "global_load_dword %2, %8, off offset:8 sc0 sc1\n\tglobal_load_dword %3, %8, off offset:12 sc0 sc1\n\t"
+                                     "global_load_dword %4, %8, off offset:16 sc0 sc1\n\tglobal_load_dword %5, %8, off offset:20 sc0 sc1\n\t"
+                                     "global_load_dword %6, %8, off offset:24 sc0 sc1\n\tglobal_load_dword %7, %8, off offset:28 sc0 sc1"
+                                     : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7) : "v"(ps) : "memory");
+                    }
+                }
                 // Literals are stored by their lanes ahead of the match copies of the same pass.  The ring is exactly as long as
                 // the farthest distance, so a store that far ahead may hit what an earlier match still has to read: position
                 // q lands on the slot of q - 32768.  A pass therefore ends with the first match whose source would be reached
@@ -843,7 +877,7 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
                     const uint32_t lim = flushed + kOutHalf;
                     uint64_t take = todo & __ballot(offv < lim), rest = todo & ~take;
                     uint32_t pend = rest ? (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)__builtin_ctzll(rest)) : o_end;
-                    const uint64_t hz = take & __ballot(k2 == 2 && offv + (kOutRing - 1) - (tw >> 11) < pend);
+                    const uint64_t hz = take & ~farm & __ballot(k2 == 2 && offv + (kOutRing - 1) - (tw >> 11) < pend);
                     if (hz) {
                         take &= (2ull << (uint32_t)__builtin_ctzll(hz)) - 1; rest = todo & ~take;
                         pend = rest ? (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)__builtin_ctzll(rest)) : o_end;
@@ -854,6 +888,29 @@ __global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restric
                     while (mm) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
                         const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)tw, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
+                        if (FAR && ((farm >> l) & 1ull)) {
+                            const uint32_t flen = (t2 >> 2) & 511u, fs = mo - (t2 >> 11) - 1;
+                            __builtin_amdgcn_wave_barrier();
+                            if ((pfm >> l) & 1ull) { // the 32 bytes lane l asked for: byte i to lane i
+                                // (the wait and the reads of the loaded registers in ONE statement: the compiler must not read -- copy -- them before the loads have landed)
+                                uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+                                asm volatile("s_waitcnt vmcnt(0)\n\t"
+                                             "v_readlane_b32 %0, %8, %16\n\tv_readlane_b32 %1, %9, %16\n\tv_readlane_b32 %2, %10, %16\n\tv_readlane_b32 %3, %11, %16\n\t"
+                                             "v_readlane_b32 %4, %12, %16\n\tv_readlane_b32 %5, %13, %16\n\tv_readlane_b32 %6, %14, %16\n\tv_readlane_b32 %7, %15, %16"
+                                             : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7)
+                                             : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "s"(l) : "memory");
+                                const uint32_t ws = (lane >> 2) & 7u;
+                                const uint32_t wv = ws == 0 ? d0 : ws == 1 ? d1 : ws == 2 ? d2 : ws == 3 ? d3 : ws == 4 ? d4 : ws == 5 ? d5 : ws == 6 ? d6 : d7;
+                                if (lane < flen) L.out[(mo + lane) & (kOutRing - 1)] = (ring_t)(uint8_t)(wv >> (8 * (lane & 3u)));
+                            } else { // longer than 32 bytes, or asked for too early: from memory now
+                                for (uint32_t i = lane; i < flen; i += 64) {
+                                    uint8_t v = 0;
+                                    if ((uint64_t)fs + i < dst_room) v = __hip_atomic_load(dst + fs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    L.out[(mo + i) & (kOutRing - 1)] = (ring_t)v;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        } else
                         copy_match(mo, (t2 >> 2) & 511u, (t2 >> 11) + 1);
                         INF_N(n_mat);
                     }
@@ -1045,8 +1102,18 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     ZGPU_HIP_CHECK(hipMemsetAsync(acc, 0, 8 * sizeof(uint64_t), st));
     RunStateHostI rs{}; rs.adler_a = 1;
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
+    // the ring: 32 KiB (every distance inside it), or -- chunks that go straight to their place in the destination, no dictionary in front -- a smaller
+    // one with the far matches read back from the destination (more segments per CU).  ZGPU_INF_RING_KB=8|16|32 picks it.
+    static int ring_kb = -1;
+    if (ring_kb < 0) { const char *v = getenv("ZGPU_INF_RING_KB"); ring_kb = v ? atoi(v) : ZGPU_INF_RING_DEFAULT_KB; if (ring_kb != 8 && ring_kb != 16) ring_kb = 32; }
+    const int ring_here = (!compact && chunk_size != kWholeStream && engine_inflate_dict_len(e) == 0) ? ring_kb : 32;
     static bool opt_in = false;
-    if (!opt_in) { hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds)); opt_in = true; }
+    if (!opt_in) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLds));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<false, 16384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsT<uint8_t, 16384>));
+        hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel_t<false, 8192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InflateLdsT<uint8_t, 8192>));
+        opt_in = true;
+    }
     hipEvent_t ev{};
     int rc_sum = 0;
     prof_span_begin(e, st, &ev);
@@ -1054,6 +1121,13 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     if (!oscr) return engine_fail(e, ZGPU_MEM_ERROR, "inflate offsets");
     for (uint64_t c0 = 0; c0 < nchunks; c0 += batch) {
         const uint32_t nb = (uint32_t)(nchunks - c0 < batch ? nchunks - c0 : batch);
+        if (ring_here == 8)
+            hipLaunchKernelGGL((inflate_kernel_t<false, 8192>), dim3(nb), dim3(128), sizeof(InflateLdsT<uint8_t, 8192>), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
+                               d_out, out_cap, status, nullptr, engine_inflate_dict(e), 0u, stream_mode, SpecArgs{});
+        else if (ring_here == 16)
+            hipLaunchKernelGGL((inflate_kernel_t<false, 16384>), dim3(nb), dim3(128), sizeof(InflateLdsT<uint8_t, 16384>), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
+                               d_out, out_cap, status, nullptr, engine_inflate_dict(e), 0u, stream_mode, SpecArgs{});
+        else
         hipLaunchKernelGGL(inflate_kernel_t<false>, dim3(nb), dim3(128), sizeof(InflateLds), st, d_in, in_bytes, d_offsets, c0, nb, last_chunk, chunk_size,
                            compact ? slots : d_out, out_cap, status, compact ? meta : nullptr, engine_inflate_dict(e), engine_inflate_dict_len(e), stream_mode, SpecArgs{});
         hipLaunchKernelGGL(inflate_reduce_kernel, dim3(1), dim3(1024), 0, st, status, nb, c0, chunk_size, acc, stream_mode, last_chunk, compact ? meta : nullptr, (uint32_t)kMsgTruncated);

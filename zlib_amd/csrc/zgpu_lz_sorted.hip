@@ -669,6 +669,14 @@ __device__ inline void stack_push(unsigned long long m, uint32_t rt, uint32_t du
                  : "=&v"(t) : "s"(m), "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(rt), "v"(dummy), "v"(entry) : "memory");
 }
 
+// LDS byte offset of the slot the lanes of m append to a stack whose top is at byte offset rt, in lane order (the other lanes get a slot they must not use)
+__device__ inline uint32_t stack_slot(unsigned long long m, uint32_t rt)
+{
+    uint32_t t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %2, %0\n\tv_lshl_add_u32 %0, %0, 2, %3" : "=&v"(t) : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "s"(rt));
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------- K2''
 // Lockstep form of the same search.  A wave takes 64 CONSECUTIVE entries of S (one work item = one block of 64 S
 // indices); lane L searches position S[wi], wi = 64*blk + L, and all lanes examine their k-th candidate S[wi-1-k] in the
@@ -926,16 +934,26 @@ extern "C" __attribute__((visibility("default"))) void zgpu_debug_walk_time(unsi
 }
 // (summed in registers, written once when the wave is done: an atomic per section would sit in the wave's memory counter and be waited for
 // by the next section that needs a load)
-#define W_T0() unsigned long long wt_prev = __builtin_readcyclecounter(), wt_fold = 0, wt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define W_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); wt_acc[i] += t_ - wt_prev - ((i) == 1 ? wt_fold : 0); if ((i) == 1) wt_acc[2] += wt_fold; wt_fold = 0; wt_prev = t_; } while (0)
+#define W_T0() unsigned long long wt_prev = __builtin_readcyclecounter(), wt_fold = 0, wt_lds = 0, wt_take = 0, wt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define W_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); wt_acc[i] += t_ - wt_prev - ((i) == 1 ? wt_fold + wt_lds + wt_take : 0); \
+                    if ((i) == 1) { wt_acc[2] += wt_fold; wt_acc[3] += wt_lds; wt_acc[7] += wt_take; } wt_fold = wt_lds = wt_take = 0; wt_prev = t_; } while (0)
 #define W_TF(stmt) do { const unsigned long long f0_ = __builtin_readcyclecounter(); stmt; wt_fold += __builtin_readcyclecounter() - f0_; } while (0)
+#define W_TL(stmt) do { const unsigned long long f0_ = __builtin_readcyclecounter(); stmt; wt_lds += __builtin_readcyclecounter() - f0_; } while (0)   // the body's batch of byte reads
+#define W_TK(stmt) do { const unsigned long long f0_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stmt; wt_take += __builtin_readcyclecounter() - f0_; } while (0) // waiting for the groups a pass asked for
 #define W_TEND() do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&walk_time[i_], wt_acc[i_]); } while (0)
 #else
 #define W_T0() do { } while (0)
 #define W_T(i) do { } while (0)
 #define W_TF(stmt) stmt
+#define W_TL(stmt) stmt
+#define W_TK(stmt) stmt
 #define W_TEND() do { } while (0)
 #endif
+// b + the high / low half of w, b | the high half of w: one instruction each (SDWA picks the half), b | (w & m)
+__device__ inline uint32_t add_w1(uint32_t b, uint32_t w) { uint32_t r; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(b), "v"(w)); return r; }
+__device__ inline uint32_t add_w0(uint32_t b, uint32_t w) { uint32_t r; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(b), "v"(w)); return r; }
+__device__ inline uint32_t or_w1(uint32_t b, uint32_t w) { uint32_t r; asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(b), "v"(w)); return r; }
+__device__ inline uint32_t and_or(uint32_t w, uint32_t m, uint32_t b) { uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(m), "v"(b)); return r; }
 __device__ inline uint32_t sel_mask(unsigned long long m, uint32_t if_set, uint32_t if_clear) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m)); return r; }
 
 // TILE (continuous stream): where the parse leaves the tile as a function of where it enters it.  The games the walkers have played (gm, one bit per game
@@ -1076,6 +1094,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
     // blocks: TILE -- one per entry, then one per 64 positions of the rest of the range
     const uint32_t chainF = cfg.chain, chainQ = cfg.chain >> 2, dbase = lds_off(d32), nblk = TILE ? tnent + (th1 - th0 - tnent + kWBlk - 1) / kWBlk : (n + kWBlk - 1) / kWBlk;
     const uint32_t wlim = TILE ? th1 : n; // a walker that arrives here, neutral, is done with the chunk / the tile
+    const bool vexact = (chainF & 7u) != 0 || (chainQ & 7u) != 0 || cfg.strategy == kRle; // a chain may end inside a group of eight with entries of its own bucket behind it (see the bodies)
     const uint32_t lanebits = lane << 16, dummy = ring + (kRing - 1) * 4;
     // walker
     uint32_t st = W_NEED, x = 0, handL = kMinMatch - 1, handM = 0, handD = 0, gstart = 0;
@@ -1246,19 +1265,23 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
                 // group -- and for all eight in lanes that examine nothing -- it reads a fixed word whose two bytes differ from scan0, so
                 // that a hit is a hit of a real candidate and no step needs the walking mask (whether a candidate is in reach is
                 // checked when it is compared in full, fold()).
-                const uint32_t scan0 = scan2;
-                const uint32_t nv = sel_mask(amask0, rem < 8 ? rem : 8, 0u);
-                const uint32_t sent = dbase + (scan0 ? kChunkMax + 8u : kChunkMax + 64u + 8u); // zero pad | the 0xFF words behind it
-                uint32_t qv[8], bb[8];
+                // Addresses straight from the halves of G0 (SDWA: no extraction).  Which of the eight are candidates at all is NOT checked here:
+                // a lane that examines nothing compares with a value no two bytes can make; a lane whose chain ends inside the group reads on into
+                // the entries below its bucket, whose hashes -- so their first three bytes -- differ from the scan string's: the full comparison
+                // (fold) finds fewer than MIN_MATCH bytes and drops them.  Only a chain cut short by the BUDGET goes on into entries of its own
+                // bucket that must not be looked at: budgets are multiples of eight (whole groups) except at level 4, in tuned configurations and
+                // for Z_RLE -- `vexact`: those take the sentinel address for the entries past the chain's end, as every body did before.
+                const uint32_t scan0 = sel_mask(amask0, scan2, 0xffffffffu);
+                uint32_t bb[8], a[8];
+                a[0] = add_w1(boff, G0.w); a[1] = add_w0(boff, G0.w); a[2] = add_w1(boff, G0.z); a[3] = add_w0(boff, G0.z); // nearest candidate = highest address
+                a[4] = add_w1(boff, G0.y); a[5] = add_w0(boff, G0.y); a[6] = add_w1(boff, G0.x); a[7] = add_w0(boff, G0.x);
+                if (vexact) { // (uniform)
+                    const uint32_t nv = rem < 8 ? rem : 8, sent = dbase + (scan2 ? kChunkMax + 8u : kChunkMax + 64u + 8u); // zero pad | the 0xFF words behind it: two bytes that differ from the scan string's
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t wd = j < 2 ? G0.w : j < 4 ? G0.z : j < 6 ? G0.y : G0.x; // nearest candidate = highest address
-                    qv[j] = (j & 1) ? wd & 0xffffu : wd >> 16;
+                    for (uint32_t j = 0; j < 8; j++) a[j] = j < nv ? a[j] : sent;
                 }
-                {
-                    uint32_t a[8], hi[8]; // (d16 loads would fill both halves of one register, but with SRAM ECC on they clear the other half)
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) a[j] = j < nv ? boff + qv[j] : sent;
+                uint32_t hi[8]; // (d16 loads would fill both halves of one register, but with SRAM ECC on they clear the other half)
+                W_TL(
                     asm volatile("ds_read_u8 %0, %16\n\tds_read_u8 %8, %16 offset:1\n\tds_read_u8 %1, %17\n\tds_read_u8 %9, %17 offset:1\n\t"
                                  "ds_read_u8 %2, %18\n\tds_read_u8 %10, %18 offset:1\n\tds_read_u8 %3, %19\n\tds_read_u8 %11, %19 offset:1\n\t"
                                  "ds_read_u8 %4, %20\n\tds_read_u8 %12, %20 offset:1\n\tds_read_u8 %5, %21\n\tds_read_u8 %13, %21 offset:1\n\t"
@@ -1266,19 +1289,56 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
                                  "s_waitcnt lgkmcnt(0)"
                                  : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]), "=&v"(bb[4]), "=&v"(bb[5]), "=&v"(bb[6]), "=&v"(bb[7]),
                                    "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
-                                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+                                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory"));
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) bb[j] |= hi[j] << 16;
-                }
+                for (uint32_t j = 0; j < 8; j++) bb[j] |= hi[j] << 16;
                 W_STAT(1, __popcll(amask0) * 8);
+                // The hits of all eight comparisons are counted first (scalar), then parked in one straight run: no branch and no fold between
+                // two candidates -- a wave's critical path through a body is what bounds the kernel, not the number of its instructions.  The stack
+                // holds 127 entries: when these do not fit on top of what is parked it is folded empty first, and the (rare: runs, zeros) body with
+                // more hits than the stack holds takes the candidates one by one as before.
+                const uint32_t lf = lanebits | firstb;
+                unsigned long long mm[8];
+                uint32_t total = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const unsigned long long m = mask_eq_u32(bb[j], scan0);
-                    if (m) {
-                        stack_push(m, (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, qv[j] | lanebits | (j == 0 ? firstb : 0u));
-                        tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(m));
-                        if (tail >= kWFoldAt) W_TF(fold());
+                for (uint32_t j = 0; j < 8; j++) { mm[j] = mask_eq_u32(bb[j], scan0); total += (uint32_t)__popcll(mm[j]); }
+                auto entry_of = [&](uint32_t j) -> uint32_t {
+                    const uint32_t wd = j < 2 ? G0.w : j < 4 ? G0.z : j < 6 ? G0.y : G0.x, lb = j == 0 ? lf : lanebits;
+                    return (j & 1) ? and_or(wd, 0xffffu, lb) : or_w1(lb, wd);
+                };
+                if (total) {
+                    if (tail + total > kRing - 1) { while (tail) W_TF(fold()); }
+                    if (total <= kRing - 1) {
+                        // (only the lanes with a hit store: the others' stores to a common dummy word were the kernel's largest source of bank conflicts)
+                        uint32_t ta[8], te[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            ta[j] = stack_slot(mm[j], ring + (tail << 2)); te[j] = entry_of(j);
+                            tail += (uint32_t)__popcll(mm[j]);
+                        }
+                        tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail);
+                        unsigned long long sv;
+                        asm volatile("s_mov_b64 %0, exec\n\t"
+                                     "s_mov_b64 exec, %17\n\tds_write_b32 %1, %9\n\ts_mov_b64 exec, %18\n\tds_write_b32 %2, %10\n\t"
+                                     "s_mov_b64 exec, %19\n\tds_write_b32 %3, %11\n\ts_mov_b64 exec, %20\n\tds_write_b32 %4, %12\n\t"
+                                     "s_mov_b64 exec, %21\n\tds_write_b32 %5, %13\n\ts_mov_b64 exec, %22\n\tds_write_b32 %6, %14\n\t"
+                                     "s_mov_b64 exec, %23\n\tds_write_b32 %7, %15\n\ts_mov_b64 exec, %24\n\tds_write_b32 %8, %16\n\t"
+                                     "s_mov_b64 exec, %0"
+                                     : "=&s"(sv)
+                                     : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]), "v"(ta[3]), "v"(ta[4]), "v"(ta[5]), "v"(ta[6]), "v"(ta[7]),
+                                       "v"(te[0]), "v"(te[1]), "v"(te[2]), "v"(te[3]), "v"(te[4]), "v"(te[5]), "v"(te[6]), "v"(te[7]),
+                                       "s"(mm[0]), "s"(mm[1]), "s"(mm[2]), "s"(mm[3]), "s"(mm[4]), "s"(mm[5]), "s"(mm[6]), "s"(mm[7]) : "memory");
+                    } else {
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            if (mm[j]) {
+                                stack_push(mm[j], (uint32_t)__builtin_amdgcn_readfirstlane(ring + (tail << 2)), dummy, entry_of(j));
+                                tail = (uint32_t)__builtin_amdgcn_readfirstlane(tail + (uint32_t)__popcll(mm[j]));
+                                if (tail >= kWFoldAt) W_TF(fold());
+                            }
+                        }
                     }
+                    while (tail >= kWFoldAt) W_TF(fold());
                 }
                 amask &= mask_gt_u32(rem, 8u); // lanes whose chain goes on (a fold may have ended others: nice_match)
                 firstb = sel_mask(amask0, 0u, firstb);
@@ -1286,7 +1346,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
             G0 = G1; G1 = G2; G2 = G3;
             left = left ? left - 1 : 0;
             if (first && jmask) { // the searches the pass started or refilled: their 32 candidates have had a body's time to arrive
-                if ((jmask >> lane) & 1ull) { G0 = F0; G1 = F1; G2 = F2; G3 = F3; left = 4; }
+                W_TK(if ((jmask >> lane) & 1ull) { G0 = F0; G1 = F1; G2 = F2; G3 = F3; left = 4; });
             }
             rem = sel_mask(amask0, rem > 8 ? rem - 8 : 0, rem);
             {   // lanes that walk on but have nothing left in registers wait for the next pass
