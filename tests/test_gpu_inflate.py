@@ -40,6 +40,45 @@ def test_inflate_oracle_streams(eng, level):
         assert eng.last_inflate.adler32 == O.adler32(data)
 
 
+def far_match_data(seed):
+    """64 KiB chunks made of 33 KiB of noise followed by copies of pieces of it at distances around 8 KiB, 16 KiB and MAX_DIST, of every kind of
+    length (up to 32 bytes a lane asks for ahead; longer ones are read when their turn comes), three bytes of noise between them"""
+    g = cases.Lcg(seed)
+    out = bytearray()
+    dists = [8190, 8191, 8192, 8193, 8194, 9000, 12000, 12288, 16382, 16383, 16384, 16385, 16386, 20000, 24576, 32000, 32505, 32506, 5000, 300, 1]
+    lens = [3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 257, 258]
+    for c in range(3):
+        chunk = bytearray(g.below(256) for _ in range(33 * 1024))
+        while len(chunk) < 65536 - 300:
+            d, n = dists[g.below(len(dists))], lens[g.below(len(lens))]
+            for i in range(n):
+                chunk.append(chunk[len(chunk) - d])
+            chunk += bytes(g.below(256) for _ in range(3))
+        chunk += bytes(g.below(256) for _ in range(65536 - len(chunk)))
+        out += chunk
+    return bytes(out[:-777])  # (a ragged last chunk)
+
+
+def test_small_ring_far_matches(eng, monkeypatch):
+    """The segment's ring is shorter than the farthest distance (8 KiB by default): matches that reach farther back read the destination.  The same
+    streams through rings of 8, 16 and 32 KiB -- identical bytes; and a destination that ends early is not read past its end."""
+    import zlib_amd
+    data = far_match_data(77)
+    for level in (9, 6, 1):
+        body, offs = oracle_stream(data, level)
+        far = 0
+        for kb in ("8", "16", "32"):
+            monkeypatch.setenv("ZGPU_INF_RING_KB", kb)
+            out = eng.inflate_host(body, offs, out_len=len(data))
+            assert out == data, (level, kb)
+            assert eng.last_inflate.adler32 == O.adler32(data)
+        monkeypatch.setenv("ZGPU_INF_RING_KB", "8")
+        with pytest.raises(zlib_amd.EngineError) as ei:
+            eng.inflate_host(body, offs, out_len=len(data) - 40000)
+        assert ei.value.code == -5
+    monkeypatch.delenv("ZGPU_INF_RING_KB")
+
+
 def test_whole_stream_segment(eng):
     """chunk_size ZGPU_WHOLE_STREAM: one raw-deflate stream of any size as a single segment (system zlib as the producer);
     a destination that is too small gets ZGPU_BUF_ERROR and the size that was needed."""

@@ -84,7 +84,8 @@ constexpr uint32_t kScanBytes = 4096; // the block finder reads the input throug
 constexpr uint32_t kFindList = 1024; // candidates listed between two rounds of the second sieve (a group of 2048 offsets yields 683 at most: one in three)
 using InflateLdsFind = InflateLdsT<uint8_t, kScanBytes + 64 + kFindList * 2>;
 static_assert(sizeof(InflateLdsFind) <= 14336, "eleven finder waves per CU");
-static_assert(sizeof(InflateLds) <= 40448, "four waves per CU");
+static_assert(sizeof(InflateLds) <= 40448, "four segments per CU");
+static_assert(10 * sizeof(InflateLdsT<uint8_t, 8192>) <= 160 * 1024, "ten segments per CU with the 8 KiB ring (five waves per SIMD: 96 registers)");
 static_assert(sizeof(InflateLdsSpec) <= 81920, "two workgroups per CU");
 
 // Wave-uniform bit reader over a ring of input dwords in LDS.
@@ -455,7 +456,7 @@ struct SpecArgs {
 // source from the destination itself, where every byte older than the ring has been flushed: the lanes that hold such matches ask for their first 32 bytes
 // when their half of the token ring is handed over, all at once, and the copy takes them from registers when its turn comes.
 template <bool SPEC, uint32_t RING = ZGPU_INF_RING>
-__global__ void __launch_bounds__(128) inflate_kernel_t(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
+__global__ void __launch_bounds__(128, (!SPEC && RING <= 8192) ? 5 : 4) inflate_kernel_t(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint64_t *__restrict__ offsets,
                                                         uint64_t chunk0, uint32_t nchunks, uint64_t last_chunk, uint32_t chunk_size_arg,
                                                         uint8_t *__restrict__ out, uint64_t out_cap, InfStatus *status, ChunkMeta *meta,
                                                         const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t stream_mode, SpecArgs sp)
@@ -1104,8 +1105,9 @@ int inflate_run(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes, const ui
     ZGPU_HIP_CHECK(hipMemcpyAsync(engine_run_state(e), &rs, sizeof rs, hipMemcpyHostToDevice, st));
     // the ring: 32 KiB (every distance inside it), or -- chunks that go straight to their place in the destination, no dictionary in front -- a smaller
     // one with the far matches read back from the destination (more segments per CU).  ZGPU_INF_RING_KB=8|16|32 picks it.
-    static int ring_kb = -1;
-    if (ring_kb < 0) { const char *v = getenv("ZGPU_INF_RING_KB"); ring_kb = v ? atoi(v) : ZGPU_INF_RING_DEFAULT_KB; if (ring_kb != 8 && ring_kb != 16) ring_kb = 32; }
+    int ring_kb = ZGPU_INF_RING_DEFAULT_KB; // (read at every call: tests/test_gpu_inflate.py runs the same streams through all three)
+    if (const char *v = getenv("ZGPU_INF_RING_KB")) ring_kb = atoi(v);
+    if (ring_kb != 8 && ring_kb != 16) ring_kb = 32;
     const int ring_here = (!compact && chunk_size != kWholeStream && engine_inflate_dict_len(e) == 0) ? ring_kb : 32;
     static bool opt_in = false;
     if (!opt_in) {
