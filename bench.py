@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--op", default="deflate", choices=["deflate", "inflate"])
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--continuous", action="store_true", help="the timed step makes ONE continuous stream (what compress2() of the reference emits) instead of independent chunks: for profiles of that path")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip inflate / level 1 / level 9 / host-buffer runs")
     return ap.parse_args()
 
@@ -198,6 +199,10 @@ def main():
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     eng.corpus_fill_device(kind, seed, rank * nchunks, nchunks, src.data_ptr())
     cap = eng.L.zgpu_deflate_bound(nbytes, 65536)
+    if a.continuous:
+        if world > 1 or a.op != "deflate":
+            sys.exit("--continuous: one GPU, deflate")
+        cap = max(cap, eng.L.zgpu_deflate_cont_bound(nbytes) + 64)
     dst = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
     lz = {"auto": gpu.LZ_AUTO, "serial": gpu.LZ_SERIAL, "parallel": gpu.LZ_PARALLEL, "sorted": gpu.LZ_SORTED, "walk": gpu.LZ_WALK, "fast": gpu.LZ_FAST, "fastwin": gpu.LZ_FASTWIN}[a.lz]
@@ -207,8 +212,8 @@ def main():
 
     def deflate_step():
         if world == 1:
-            state["res"] = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP,
-                                              lz_impl=lz, d_offsets=offs.data_ptr(), stream=stream)
+            state["res"] = eng.deflate_device(src.data_ptr(), nbytes, a.level, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP | (gpu.F_CONTINUOUS if a.continuous else 0),
+                                              lz_impl=lz, d_offsets=None if a.continuous else offs.data_ptr(), stream=stream)
             return
         # N > 1: every rank emits the raw body of its chunk range (BFINAL only on the last rank's last chunk); rank 0 gathers
         # the bodies over RCCL and frames them into one RFC 1950 stream (zlib_amd/shard.py)
@@ -330,19 +335,19 @@ def main():
             "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s %.2f GiB per GPU, 64 KiB independent chunks, level %d, bit-exact vs zlib 1.2.3" % (
-                a.workload, nbytes / 2**30, a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
+            "config": {"workload": "%s %.2f GiB per GPU, %s, level %d, bit-exact vs zlib 1.2.3" % (
+                a.workload, nbytes / 2**30, "ONE continuous stream" if a.continuous else "64 KiB independent chunks", a.level), "op": a.op, "lz": a.lz, "chunks_per_gpu": nchunks,
                 "compression_ratio": round(ratio, 4), "stream_bytes": int(res.out_bytes),
                 "gathered_bytes": int(state.get("gathered", res.out_bytes)), "gather": comm_note,
                 **({"rehearsal": "ZAMD_BENCH_SHARE_GPU: all ranks on one GPU, no measurement"} if share else {}),
                 "chunks_checked_against_reference_hashes": (sum(per_rank["chunks_checked_against_reference_hashes"]) if per_rank else
-                                                            check_sampled_chunks(torch, dst, offs, nchunks, 0, a.level, a.workload) if a.op == "deflate" else None),
+                                                            check_sampled_chunks(torch, dst, offs, nchunks, 0, a.level, a.workload) if a.op == "deflate" and not a.continuous else None),
                 **({"per_rank": per_rank} if per_rank else {})},
-            "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, a.op, a.level),
+            "roofline": roofline_of(prof, a.steps, nbytes, res.out_bytes, "deflate-continuous" if a.continuous else a.op, a.level),
         }
     # ---- the other configurations of BASELINE.json on the same input, outside the timed region of the headline (N = 1 only):
     #      inflate of the headline's stream (config 4), level 1 and level 9 (config 3), and the host-buffer entry point (PCIe included)
-    if world == 1 and a.op == "deflate" and not a.no_extras:
+    if world == 1 and a.op == "deflate" and not a.no_extras and not a.continuous:
         extra = {}
         z_len = state["res"].out_bytes
         offs2 = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)

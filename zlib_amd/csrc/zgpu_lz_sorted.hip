@@ -1359,6 +1359,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         }
         W_T(1);
     }
+#if ZGPU_WTHREADS == 512 // (other workgroup sizes: experiments with the walkers alone, MODE 0)
     if (TILE) {
         __syncthreads(); // every walker of the tile is done: gm / gs are complete
         tile_exits<kWThreads>(reinterpret_cast<uint8_t *>(lds), gm, gs, th0, th1, tnent_all, tg.exits + (size_t)c * kTileExitStride, tid);
@@ -1377,6 +1378,7 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
         uint32_t &sh_entry = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry), &sh_exit = *reinterpret_cast<uint32_t *>(pl + kP2OffEntry + 4);
 #include "zgpu_lz_parse_body.inc"
     }
+#endif
 }
 
 // ======================================================================================================================================
