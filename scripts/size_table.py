@@ -12,7 +12,7 @@ e = zlib_amd.Engine(0)
 nmax = 16384
 src = torch.empty(nmax * 65536, dtype=torch.uint8, device="cuda")
 e.corpus_fill_device(0, 0x5EED5117, 0, nmax, src.data_ptr())
-cap = e.L.zgpu_deflate_bound(src.numel(), 65536)
+cap = max(e.L.zgpu_deflate_bound(src.numel(), 65536), e.L.zgpu_deflate_cont_bound(src.numel()) + 64)
 dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 back = torch.empty(src.numel(), dtype=torch.uint8, device="cuda")
 offs = torch.empty(nmax + 1, dtype=torch.int64, device="cuda")
@@ -26,7 +26,7 @@ def best_of(f, k=5):
     return b
 
 
-print("%8s %22s %22s %22s %22s" % ("MiB", "level 1", "level 4", "level 6", "inflate (of level 6)"))
+print("%8s %22s %22s %22s %22s | one continuous stream: %19s %22s %22s" % ("MiB", "level 1", "level 4", "level 6", "inflate (of level 6)", "level 1", "level 4", "level 6"))
 for mib in (1, 4, 16, 64, 256, 1024):
     n = mib << 20
     row = []
@@ -37,4 +37,7 @@ for mib in (1, 4, 16, 64, 256, 1024):
     d = best_of(lambda: e.inflate_device(dst.data_ptr(), r.out_bytes, offs.data_ptr(), n >> 16, back.data_ptr(), n))
     assert torch.equal(back[:n], src[:n])
     row.append("%7.2f ms %6.2f GiB/s" % (d * 1e3, n / d / 2**30))
-    print("%8d %22s %22s %22s %22s" % (mib, *row), flush=True)
+    for lv in (1, 4, 6):
+        d = best_of(lambda: e.deflate_device(src.data_ptr(), n, lv, dst.data_ptr(), cap, flags=gpu.F_FINAL | gpu.F_CONTINUOUS), 3)
+        row.append("%7.2f ms %6.2f GiB/s" % (d * 1e3, n / d / 2**30))
+    print("%8d %22s %22s %22s %22s | %22s %22s %22s" % (mib, *row), flush=True)
