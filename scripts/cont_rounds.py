@@ -7,7 +7,8 @@ gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n = int(gib * 2**30) // 65536 * 65536
 src = torch.empty(n, dtype=torch.uint8, device="cuda")
-eng.corpus_fill_device(0, 0x5EED5117, 0, n // 65536, src.data_ptr())
+kind = int(os.environ.get("KIND", "0"))
+eng.corpus_fill_device(kind, 0x5EED5117 if kind == 0 else 0x10C7E47, 0, n // 65536, src.data_ptr())
 cap = eng.L.zgpu_deflate_cont_bound(n) + 64
 dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 os.environ["ZGPU_FAST_TRACE"] = "1"

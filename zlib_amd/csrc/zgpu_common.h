@@ -141,6 +141,10 @@ struct FastTiles {
     const uint32_t *list;                          // the tiles to parse in this round (round 0: nullptr = all of the batch): workgroup w works on tile list[w]
     uint32_t *low_out;                             // the feed's first tile also says which of its local positions 0 .. 32511 are in the chains (history and, at a stream's start, its own)
     uint32_t *dbg;                                 // (ZGPU_FAST_TRACE: eight words per tile about what changed)
+    // what a tile's current results were made from: the history's bits it used [tile][kInsWords] and where it entered; kept[tile]: this round's parse stopped
+    // early because nothing it could reach had changed -- its results stand, its buffers are not flipped (nullptr: every active tile is parsed to its end)
+    uint32_t *used_ins; uint16_t *entry_used; uint8_t *kept;
+    uint32_t *stat;                                // (ZGPU_FAST_TRACE) [0] active tiles with the entry they had, [1] parses stopped early, [2] ... that met a different token first, [3] ... with changes out of reach of nothing
 };
 
 // One block of a continuous stream (blocks are cut every 16383 tokens counted from the start of the STREAM, h/deflate.h:313): filled in by cont_table_kernel,

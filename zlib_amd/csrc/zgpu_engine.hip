@@ -40,7 +40,7 @@ void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastT
                              hipStream_t st);
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st);
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
-                      uint32_t *count, uint32_t *list, hipStream_t st);
+                      uint32_t *count, uint32_t *list, const uint8_t *kept, hipStream_t st);
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
                         const uint32_t *low, hipStream_t st);
 void launch_fast_hist(const uint32_t *before, const uint32_t *last, uint32_t x0, uint32_t count, uint32_t *out, hipStream_t st);
@@ -106,7 +106,7 @@ struct zgpu_engine {
     // ... levels 1-3: the rounds of fastwin_tile_kernel
     uint32_t cf_tiles = 0;
     uint16_t *cf_exit_a = nullptr, *cf_exit_b = nullptr; uint32_t *cf_ins0 = nullptr, *cf_ins1 = nullptr, *cf_prev = nullptr, *cf_prev2 = nullptr, *cf_hist = nullptr, *cf_count = nullptr;
-    uint8_t *cf_cur = nullptr, *cf_act_a = nullptr, *cf_act_b = nullptr, *cf_changed = nullptr; uint32_t *cf_list_a = nullptr, *cf_list_b = nullptr;
+    uint8_t *cf_cur = nullptr, *cf_act_a = nullptr, *cf_act_b = nullptr, *cf_changed = nullptr, *cf_kept = nullptr; uint32_t *cf_list_a = nullptr, *cf_list_b = nullptr, *cf_used = nullptr; uint16_t *cf_entry_used = nullptr;
     hipStream_t ct_stream = nullptr; hipEvent_t ct_ev_a[2] = {nullptr, nullptr}, ct_ev_b[2] = {nullptr, nullptr}; // levels 4-9: a batch's blocks are made on a second stream under the next batch's walkers
     uint64_t cf_rounds = 0, cf_tile_parses = 0; // (diagnostic: rounds and tile parses since the engine was made)
     // profiling
@@ -552,6 +552,7 @@ static int ensure_fast_ws(zgpu_engine *e, uint32_t batch_tiles)
     if (batch_tiles > e->cf_tiles) {
         hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed);
         hipFree(e->cf_list_a); hipFree(e->cf_list_b); e->cf_list_a = e->cf_list_b = nullptr;
+        hipFree(e->cf_kept); hipFree(e->cf_used); hipFree(e->cf_entry_used); e->cf_kept = nullptr; e->cf_used = nullptr; e->cf_entry_used = nullptr;
         e->cf_exit_a = e->cf_exit_b = nullptr; e->cf_ins0 = e->cf_ins1 = nullptr; e->cf_cur = e->cf_act_a = e->cf_act_b = e->cf_changed = nullptr; e->cf_tiles = 0;
         if ((rc = dev_alloc(e, &e->cf_exit_a, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_exit_b, (size_t)batch_tiles))) return rc;
@@ -563,6 +564,9 @@ static int ensure_fast_ws(zgpu_engine *e, uint32_t batch_tiles)
         if ((rc = dev_alloc(e, &e->cf_changed, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_list_a, (size_t)batch_tiles))) return rc;
         if ((rc = dev_alloc(e, &e->cf_list_b, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_kept, (size_t)batch_tiles))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_used, (size_t)batch_tiles * kInsWords))) return rc;
+        if ((rc = dev_alloc(e, &e->cf_entry_used, (size_t)batch_tiles))) return rc;
         e->cf_tiles = batch_tiles;
     }
     return ZGPU_OK;
@@ -581,11 +585,17 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
         FastTiles ft{};
         ft.exit_cur = e->cf_exit_a; ft.exit_new = e->cf_exit_b; ft.ins0 = ft.ins0w = e->cf_ins0; ft.ins1 = ft.ins1w = e->cf_ins1; ft.cur = e->cf_cur; ft.active = act; ft.changed = e->cf_changed;
         ft.prev_ins = e->cf_prev; ft.round = round; ft.list = list; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
+        static int keep = -1; // ZGPU_FAST_KEEP=0: every active tile is parsed to its end (A/B runs)
+        if (keep < 0) { const char *v = getenv("ZGPU_FAST_KEEP"); keep = v ? atoi(v) : 1; }
+        if (keep) { ft.used_ins = e->cf_used; ft.entry_used = e->cf_entry_used; ft.kept = e->cf_kept; }
         static uint32_t *dbg = nullptr;
         const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
         if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
         ft.dbg = trace && nb <= 65536 ? dbg : nullptr;
         if (ft.dbg) hipMemsetAsync(dbg, 0xff, (size_t)nb * 32, st);
+        static uint32_t *dstat = nullptr;
+        if (trace && !dstat) hipMalloc(reinterpret_cast<void **>(&dstat), 32);
+        if (trace) { hipMemsetAsync(dstat, 0, 32, st); ft.stat = dstat; }
         launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, ngrid, st);
         if (ft.dbg) {
             std::vector<uint32_t> h((size_t)nb * 8);
@@ -593,7 +603,7 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
             for (uint32_t c = 0; c < nb && c < 40; c++) if (h[c * 8] != 0xffffffffu)
                 fprintf(stderr, "   tile %u: %u words differ (%u .. %u), exit %u (was %u), entry %u, %u tokens\n", c, h[c * 8 + 1], h[c * 8 + 2], h[c * 8 + 3], h[c * 8 + 4], h[c * 8 + 5], h[c * 8 + 6], h[c * 8 + 7]);
         }
-        launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, list_next, st);
+        launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, list_next, ft.kept, st);
         uint32_t active = 0;
         ZGPU_HIP_CHECK(hipMemcpyAsync(&active, e->cf_count, 4, hipMemcpyDeviceToHost, st));
         ZGPU_HIP_CHECK(hipStreamSynchronize(st));
@@ -608,7 +618,11 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
             ZGPU_HIP_CHECK(hipStreamSynchronize(st));
             active = nb - 1;
         }
-        if (getenv("ZGPU_FAST_TRACE")) fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again\n", round, active, nb);
+        if (trace) {
+            uint32_t hs[8] = {};
+            hipMemcpy(hs, dstat, 32, hipMemcpyDeviceToHost);
+            fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again (this round: %u entered where they had, %u stopped early, %u met a different token, %u had changes within reach to the end)\n", round, active, nb, hs[0], hs[1], hs[2], hs[3]);
+        }
         if (active == 0) break;
         e->cf_tile_parses += active;
         uint8_t *x = act; act = act_next; act_next = x;
@@ -861,7 +875,7 @@ void zgpu_engine_destroy(zgpu_engine *e)
     hipFree(e->ct_exits); hipFree(e->ct_entry); hipFree(e->ct_comp); hipFree(e->ct_gentry); hipFree(e->ct_tokoff); hipFree(e->ct_T); hipFree(e->ct_carry); hipFree(e->ct_carry_in); hipFree(e->ct_blk);
     hipFree(e->ct_pos); hipFree(e->ct_slots); hipFree(e->ct_st); hipFree(e->ct_ckmeta); hipFree(e->ct_excl);
     hipFree(e->cf_exit_a); hipFree(e->cf_exit_b); hipFree(e->cf_ins0); hipFree(e->cf_ins1); hipFree(e->cf_prev); hipFree(e->cf_prev2); hipFree(e->cf_hist); hipFree(e->cf_count);
-    hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed); hipFree(e->cf_list_a); hipFree(e->cf_list_b);
+    hipFree(e->cf_cur); hipFree(e->cf_act_a); hipFree(e->cf_act_b); hipFree(e->cf_changed); hipFree(e->cf_list_a); hipFree(e->cf_list_b); hipFree(e->cf_kept); hipFree(e->cf_used); hipFree(e->cf_entry_used);
     hipFree(e->stage_in); hipFree(e->stage_out); hipFree(e->inf_status); hipFree(e->inf_meta); hipFree(e->inf_offs); hipFree(e->inf_slots); hipFree(e->inf_dict);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto ev : e->copy_ev) hipEventDestroy(ev);

@@ -424,9 +424,31 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
     const uint32_t tok_from = warm ? h0 : 0u;                                                            // tokens in front of this position are the warm-up's
     const uint32_t *ins_in = warm ? nullptr : (c == 0 ? ft.prev_ins : (ft.cur[c - 1] ? ft.ins1 : ft.ins0) + (size_t)(c - 1) * kInsWords);
 
+    // A tile that is parsed again because its predecessor's results changed usually finds nothing of that within its reach: the changes sit where the predecessor's
+    // own start was a guess, ~32 KiB back.  With the same entry as last time and the highest changed history bit at position md, a token that starts behind
+    // md + MAX_DIST cannot examine a changed bit (deflate.c:1037-1038, 1163: candidates at most MAX_DIST back) -- so once the parse has passed that point having
+    // made, token for token, what it made last time, the rest of the tile comes out as before (same history within reach, same own bits, by induction) and the
+    // parse stops: the tile's results stand.  A token that differs sends the parse to the tile's end as before.
+    uint32_t stop_at = ~0u, old_ntok = 0, old_ent = 0;
+    uint32_t *used = ft.used_ins ? ft.used_ins + (size_t)c * kInsWords : nullptr;
+    if (used && !warm && c != 0 && ft.round != 0 && entry_pos == ft.entry_used[c]) {
+        uint32_t md = 0;
+        for (uint32_t i = lane; i < kInsWords; i += 64) {
+            uint32_t x = ins_in[i] ^ used[i];
+            const uint32_t lo = i * 32;
+            if (lo >= entry_pos) x = 0; else if (entry_pos - lo < 32) x &= (1u << (entry_pos - lo)) - 1u; // (the bits are valid below the entry)
+            if (x) { const uint32_t hi = lo + 32u - (uint32_t)__builtin_clz(x); md = hi > md ? hi : md; }  // (highest changed position + 1)
+        }
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)md, o); md = y > md ? y : md; }
+        stop_at = md ? md - 1 + kMaxDist : 0u;
+        if (ft.stat && lane == 0) { atomicAdd(&ft.stat[0], 1u); if (stop_at >= h1) atomicAdd(&ft.stat[3], 1u); }
+        old_ntok = meta[c].ntok; old_ent = tg.entry[g.chunk0 + c];
+    }
+    bool same = true; // the tokens made so far are the ones the tile had
+
     for (uint32_t i = lane; i < kFwFlagWords; i += 64) flags[i] = 0;
     __syncthreads();
-    if (ins_in) { // the history's bits, by S index: every position in front of the entry that the predecessor found in the chains
+    if (ins_in && !(stop_at == 0u)) { // the history's bits, by S index: every position in front of the entry that the predecessor found in the chains
         for (uint32_t q0 = 0; q0 < entry_pos; q0 += 256) {
             uint32_t iv[4]; bool on[4];
 #pragma unroll
@@ -471,6 +493,11 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
     __syncthreads();
 
     for (uint32_t win = win0; win < nwin && pos < h1; win++) {
+        if (stop_at != ~0u && same && pos > stop_at) { // (uniform) nothing that changed is within reach any more, and nothing has come out differently: the results stand
+            for (uint32_t i = lane; i < kInsWords; i += 64) used[i] = ins_in[i];
+            if (lane == 0) { ft.kept[c] = 1; ft.changed[c] = 0; ft.exit_new[c] = ft.exit_cur[c]; if (ft.stat) atomicAdd(&ft.stat[1], 1u); }
+            return;
+        }
         const uint32_t w0 = win * 64, p = w0 + lane;
         const bool skip = pos >= w0 + 64;
         if (!skip) {
@@ -616,11 +643,15 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
             {   // the accepted tokens (the warm-up's, in front of h0, are dropped)
                 const uint32_t lo_l = tok_from > w0 ? (tok_from - w0 < 64 ? tok_from - w0 : 64u) : 0u;
                 const uint64_t Tv = lo_l >= 64 ? 0ull : Tacc & (~0ull << lo_l);
+                bool neq = false;
                 if (Tv & lane_bit) {
-                    const uint32_t ln = res & kResLen;
-                    tok[ntok + (uint32_t)__builtin_popcountll(Tv & lanes_below)] = ln == 1 ? tok_lit(own_byte) : tok_match(p - mstart, ln - kMinMatch);
+                    const uint32_t ln = res & kResLen, ti = ntok + (uint32_t)__builtin_popcountll(Tv & lanes_below);
+                    const uint32_t nv = ln == 1 ? tok_lit(own_byte) : tok_match(p - mstart, ln - kMinMatch);
+                    if (stop_at != ~0u && same) neq = ti >= old_ntok || tok[ti] != nv;
+                    tok[ti] = nv;
                 }
-                if (ent_used == ~0u && Tv != 0) ent_used = w0 + (uint32_t)__builtin_ctzll(Tv) - h0;
+                if (stop_at != ~0u && same && __builtin_amdgcn_ballot_w64(neq) != 0) { same = false; if (ft.stat && lane == 0) atomicAdd(&ft.stat[2], 1u); }
+                if (ent_used == ~0u && Tv != 0) { ent_used = w0 + (uint32_t)__builtin_ctzll(Tv) - h0; if (stop_at != ~0u && ent_used != old_ent) same = false; }
                 ntok += (uint32_t)__builtin_popcountll(Tv);
             }
             if (Lacc >= 64 || Lacc >= lend) {
@@ -704,6 +735,18 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
         }
         for (uint32_t i = kTileStride / 32 + lane; i < kInsWords; i += 64) ft.low_out[i] = 0;
     }
+    if (used) { // what these results were made from
+        if (warm) { // the warm-up's own account of the history
+            for (uint32_t q0 = 0; q0 < kInsWords * 32; q0 += 64) {
+                const uint32_t q = q0 + lane;
+                bool on = false;
+                if (q < pos && q < npos) { const uint32_t b = 65536u - (ir[q] & 0xffffu) - 1u; on = (flags[b >> 5] >> (b & 31u)) & 1u; }
+                const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+                if (lane == 0) { used[q0 >> 5] = (uint32_t)m; used[(q0 >> 5) + 1] = (uint32_t)(m >> 32); }
+            }
+        } else if (ins_in && c != 0) for (uint32_t i = lane; i < kInsWords; i += 64) used[i] = ins_in[i];
+        if (lane == 0) { ft.entry_used[c] = (uint16_t)(warm ? h0 + ent_used : entry_pos); ft.kept[c] = 0; }
+    }
     if (lane == 0 && ft.dbg) { uint32_t *d = ft.dbg + (size_t)c * 8; d[0] = ft.round; d[1] = dbg_n; d[2] = dbg_first; d[3] = dbg_last; d[4] = exit_k; d[5] = ft.exit_cur[c]; d[6] = entry_pos; d[7] = ntok; }
     if (lane == 0) {
         meta[c].ntok = ntok; meta[c].in_bytes = 0;
@@ -742,11 +785,11 @@ __global__ void __launch_bounds__(256) fast_init_kernel(uint8_t *cur, uint8_t *a
 }
 // behind a round: the tiles that were parsed make their new results current; a tile is parsed again when its predecessor's results have changed
 __global__ void __launch_bounds__(256) fast_flip_kernel(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new,
-                                                        uint32_t n, uint32_t round, uint32_t *count, uint32_t *list)
+                                                        uint32_t n, uint32_t round, uint32_t *count, uint32_t *list, const uint8_t *kept)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (round == 0 || active[i]) { cur[i] ^= 1; exit_cur[i] = exit_new[i]; }
+    if (round == 0 || (active[i] && !(kept && kept[i]))) { cur[i] ^= 1; exit_cur[i] = exit_new[i]; } // (a tile whose parse stopped early keeps its results where they are)
     const bool nx = i >= 1 && (round == 0 || (active[i - 1] && changed[i - 1]));
     active_next[i] = nx ? 1 : 0;
     if (nx) list[atomicAdd(count, 1u)] = i; // (any order: the tiles of a round do not depend on each other)
@@ -781,10 +824,10 @@ __global__ void __launch_bounds__(256) fast_hist_kernel(const uint32_t *before, 
 }
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st) { hipLaunchKernelGGL(fast_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, exit_cur, n); }
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
-                      uint32_t *count, uint32_t *list, hipStream_t st)
+                      uint32_t *count, uint32_t *list, const uint8_t *kept, hipStream_t st)
 {
     hipMemsetAsync(count, 0, 4, st);
-    hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count, list);
+    hipLaunchKernelGGL(fast_flip_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, active_next, changed, exit_cur, exit_new, n, round, count, list, kept);
 }
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
                         const uint32_t *low, hipStream_t st)
