@@ -1,5 +1,5 @@
-"""Condense the round's rocprofv3 counter summaries (profiles/r03_*_summary.txt, written by scripts/prof_round.sh + prof_summarize.py) into
-profiles/r03_traffic.json: HBM-side bytes per launch of the dominant kernel of every bench leg, which bench.py quotes as roofline.traffic / .limiter."""
+"""Condense the round's rocprofv3 counter summaries (profiles/r04_*_summary.txt, written by scripts/prof_round.sh + prof_summarize.py) into
+profiles/r04_traffic.json: HBM-side bytes per launch of the dominant kernel of every bench leg, which bench.py quotes as roofline.traffic / .limiter."""
 import json
 import os
 import re
@@ -38,22 +38,22 @@ def entry(path, kernel, limiter):
 
 
 out = {
-    "deflate-L6-silesia-mix-4gib-match": entry("r03_final_4gib_L6_summary.txt", "walk_kernel<true>",
-        "vector-ALU issue and the latency of scattered S lines: walk_kernel<true> (parse-driven search + the rest of the parse); bodies 58 % / folds 14 % / passes 29 % of a wave's cycles "
-        "(profiles/r03_walk_phases_levels_4_6_9.txt); not HBM bandwidth, but 50x the algorithmic bytes cross the fabric"),
-    "deflate-L9-silesia-mix-4gib-match": entry("r03_L9_4gib_summary.txt", "walk_kernel<true>",
-        "the same kernel with 4096-deep chains: bodies 67 % of a wave's cycles, 44 candidate steps per byte (profiles/r03_walk_phases_levels_4_6_9.txt)"),
-    "deflate-L1-silesia-mix-4gib-lz_serial": entry("r03_L1_4gib_lz_serial_summary.txt", "lz_serial_kernel",
+    "deflate-L6-silesia-mix-4gib-match": entry("r04_final_4gib_L6_summary.txt", "walk_kernel<1>",
+        "the dependent chain through a body of the walkers, not a pipe: VALU 64 %, LDS 40 % (half of it bank conflicts), scalar 36 % of a CU's cycles busy, a wave half its cycles in s_waitcnt; "
+        "bodies 49 % / folds 14 % / passes 34 % / byte reads 7 % / waiting for groups 4 % of a wave's cycles (profiles/r04_walk_phases.txt); removing 5 % of the instructions gained 2.4 % "
+        "(DESIGN.md section 4 'What round 4 tried on the walkers'); not HBM bandwidth, but 50x the algorithmic bytes cross the fabric"),
+    "deflate-L9-silesia-mix-4gib-match": entry("r04_L9_4gib_summary.txt", "walk_kernel<1>",
+        "the same kernel with 4096-deep chains: bodies 61 % of a wave's cycles, 44 candidate steps per byte (profiles/r04_walk_phases.txt)"),
+    "deflate-L1-silesia-mix-4gib-lz_serial": entry("r04_L1_4gib_summary.txt", "lz_serial_kernel<false>",
         "latency of the slowest chunks' chains of dependent scattered reads (head, candidate bytes, prev): one lane per chunk, a launch lasts as long as the chunk with the most "
-        "tokens; the 5 % of chunks that do not compress go to the wave-per-chunk kernel after 4 KiB (377 -> 232 ms, profiles/r03_serial_loop_by_class.txt, r03_hand_on_levels_1_3.txt); "
-        "that kernel, which serves launches below 1.25 GiB alone, is issue-bound instead (one wave per SIMD)"),
-    "deflate-L1-silesia-mix-1gib-match": entry("r03_L1_fastwin_1gib_summary.txt", "fastwin_kernel<4, 8>",
-        "instruction issue of a lone wave per SIMD (one instruction every 5-6 cycles), three chunks per CU (47 KiB of LDS each): 12 000 cycles per 64-position window, "
-        "evaluation 31 % / scalar walk 49 % (profiles/r03_fastwin_phases.txt)"),
-    "inflate-L6-silesia-mix-4gib-inflate": entry("r03_inflate_4gib_L6_summary.txt", "inflate_kernel_t<false>",
-        "latency of the per-token chains of one reader and one writer wave per segment, four segments per CU (40 KiB of LDS each); traffic 1.0x the algorithmic bytes; not HBM.  "
-        "With a 16 / 8 KiB ring (output void, timing only) the kernel takes 67 / 60 ms instead of 84: residency is worth at most 1.3-1.45x"),
+        "tokens; the chunks that do not compress go to the wave-per-chunk kernel after 4 KiB (unchanged since round 3)"),
+    "deflate-continuous-L6-silesia-mix-4gib-match": entry("r04_continuous_4gib_L6_summary.txt", "walk_kernel<2>",
+        "the walkers of a tile (32 KiB of new positions behind 32 KiB of history): a chunk's fixed costs -- staging 64 KiB, a thousand walker starts, ramp and tail of the walker loop, "
+        "the exit function -- for half a chunk's work; the tile sort (every byte twice) and the tokens from the true entries (parse2_kernel<true, true>) are kernels of their own"),
+    "inflate-L6-silesia-mix-4gib-inflate": entry("r04_inflate_4gib_L6_summary.txt", "inflate_kernel_t<false, 8192u>",
+        "latency of the per-token chains of one reader and one writer wave per segment, ten segments per CU (15 KiB of LDS each, 96 registers a lane); matches that reach farther back "
+        "than the 8 KiB ring (13 %) read the destination; not HBM"),
 }
-json.dump(out, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "r04_traffic.json"), "w"), indent=1)
 for k, v in out.items():
-    print("%-42s traffic %7.2f GB per launch (fetch %7.2f, write %6.2f)  %s" % (k, v["traffic_bytes_per_launch"] / 1e9, v["fetch_bytes_per_launch"] / 1e9, v["write_bytes_per_launch"] / 1e9, v.get("counters")))
+    print("%-46s traffic %7.2f GB per launch (fetch %7.2f, write %6.2f)  %s" % (k, v["traffic_bytes_per_launch"] / 1e9, v["fetch_bytes_per_launch"] / 1e9, v["write_bytes_per_launch"] / 1e9, v.get("counters")))

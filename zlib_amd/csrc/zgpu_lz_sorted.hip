@@ -1272,9 +1272,15 @@ __global__ void __launch_bounds__(kWThreads, kWThreads / 128) walk_kernel(ChunkG
                 // bucket that must not be looked at: budgets are multiples of eight (whole groups) except at level 4, in tuned configurations and
                 // for Z_RLE -- `vexact`: those take the sentinel address for the entries past the chain's end, as every body did before.
                 const uint32_t scan0 = sel_mask(amask0, scan2, 0xffffffffu);
-                uint32_t bb[8], a[8];
-                a[0] = add_w1(boff, G0.w); a[1] = add_w0(boff, G0.w); a[2] = add_w1(boff, G0.z); a[3] = add_w0(boff, G0.z); // nearest candidate = highest address
-                a[4] = add_w1(boff, G0.y); a[5] = add_w0(boff, G0.y); a[6] = add_w1(boff, G0.x); a[7] = add_w0(boff, G0.x);
+                uint32_t bb[8], a[8], boff_e;
+                boff_e = boff;
+                if (!vexact) { // the lanes that examine nothing read ONE common word (a broadcast): with whatever their registers held they were a third of the kernel's bank conflicts
+                    const uint32_t boff_i = dbase + kChunkMax + 8u;
+                    G0.x = sel_mask(amask0, G0.x, 0u); G0.y = sel_mask(amask0, G0.y, 0u); G0.z = sel_mask(amask0, G0.z, 0u); G0.w = sel_mask(amask0, G0.w, 0u);
+                    boff_e = sel_mask(amask0, boff, boff_i);
+                }
+                a[0] = add_w1(boff_e, G0.w); a[1] = add_w0(boff_e, G0.w); a[2] = add_w1(boff_e, G0.z); a[3] = add_w0(boff_e, G0.z); // nearest candidate = highest address
+                a[4] = add_w1(boff_e, G0.y); a[5] = add_w0(boff_e, G0.y); a[6] = add_w1(boff_e, G0.x); a[7] = add_w0(boff_e, G0.x);
                 if (vexact) { // (uniform)
                     const uint32_t nv = rem < 8 ? rem : 8, sent = dbase + (scan2 ? kChunkMax + 8u : kChunkMax + 64u + 8u); // zero pad | the 0xFF words behind it: two bytes that differ from the scan string's
 #pragma unroll
