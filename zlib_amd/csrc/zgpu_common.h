@@ -138,6 +138,7 @@ struct FastTiles {
     const uint8_t *active; uint8_t *changed;       // [tile]
     const uint32_t *prev_ins;                      // the bits in front of the batch's first tile (its local positions 0 .. 33023): the feed's history, or the batch before
     uint32_t round;
+    uint32_t warm_mode;                            // 1: the launch's tiles (but the batch's first) start from nothing and parse their history as well; 0: from where the tile in front ended, with its bits
     const uint32_t *list;                          // the tiles to parse in this round (round 0: nullptr = all of the batch): workgroup w works on tile list[w]
     uint32_t *low_out;                             // the feed's first tile also says which of its local positions 0 .. 32511 are in the chains (history and, at a stream's start, its own)
     uint32_t *dbg;                                 // (ZGPU_FAST_TRACE: eight words per tile about what changed)

@@ -39,6 +39,7 @@ void launch_sort_tiles(const ChunkGeom &g, void *workspace, ChunkMeta *meta, hip
 void launch_lz_fastwin_tiles(const ChunkGeom &g, const TileGeom &tg, const FastTiles &ft, LevelCfg cfg, const uint16_t *S, const uint32_t *ir, uint32_t *tokens, ChunkMeta *meta, uint32_t ngrid,
                              hipStream_t st);
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st);
+void launch_fast_flip_list(uint8_t *cur, uint16_t *exit_cur, const uint16_t *exit_new, const uint32_t *list, uint32_t n, hipStream_t st);
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
                       uint32_t *count, uint32_t *list, const uint8_t *kept, hipStream_t st);
 void launch_fast_finish(const uint8_t *cur, const uint16_t *exit_cur, const uint32_t *ins0, const uint32_t *ins1, uint32_t n, uint16_t *entry_after, uint32_t *prev_ins, uint32_t *prev_prev_ins,
@@ -581,21 +582,63 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
     launch_fast_init(e->cf_cur, e->cf_act_a, e->cf_exit_a, nb, st);
     uint8_t *act = e->cf_act_a, *act_next = e->cf_act_b;
     uint32_t *list = nullptr, *list_next = e->cf_list_a, ngrid = nb;
-    for (uint32_t round = 0;; round++) {
-        FastTiles ft{};
+    static uint32_t *dbg = nullptr, *dstat = nullptr;
+    const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
+    if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
+    if (trace && !dstat) hipMalloc(reinterpret_cast<void **>(&dstat), 32);
+    static int keep = -1; // ZGPU_FAST_KEEP=0: every active tile is parsed to its end (A/B runs)
+    if (keep < 0) { const char *v = getenv("ZGPU_FAST_KEEP"); keep = v ? atoi(v) : 1; }
+    auto fill = [&](FastTiles &ft, uint32_t round, const uint32_t *lst) {
         ft.exit_cur = e->cf_exit_a; ft.exit_new = e->cf_exit_b; ft.ins0 = ft.ins0w = e->cf_ins0; ft.ins1 = ft.ins1w = e->cf_ins1; ft.cur = e->cf_cur; ft.active = act; ft.changed = e->cf_changed;
-        ft.prev_ins = e->cf_prev; ft.round = round; ft.list = list; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
-        static int keep = -1; // ZGPU_FAST_KEEP=0: every active tile is parsed to its end (A/B runs)
-        if (keep < 0) { const char *v = getenv("ZGPU_FAST_KEEP"); keep = v ? atoi(v) : 1; }
+        ft.prev_ins = e->cf_prev; ft.round = round; ft.list = lst; ft.low_out = e->cf_hist; // (cf_hist: free until the feed's hand-over is put together)
         if (keep) { ft.used_ins = e->cf_used; ft.entry_used = e->cf_entry_used; ft.kept = e->cf_kept; }
-        static uint32_t *dbg = nullptr;
-        const bool trace = getenv("ZGPU_FAST_TRACE") != nullptr;
-        if (trace && !dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 65536 * 32);
         ft.dbg = trace && nb <= 65536 ? dbg : nullptr;
-        if (ft.dbg) hipMemsetAsync(dbg, 0xff, (size_t)nb * 32, st);
-        static uint32_t *dstat = nullptr;
-        if (trace && !dstat) hipMalloc(reinterpret_cast<void **>(&dstat), 32);
         if (trace) { hipMemsetAsync(dstat, 0, 32, st); ft.stat = dstat; }
+    };
+    // Round 0 in K phases (ZGPU_FAST_RUN=K; 1: all tiles at once, as until round 4).  A tile that starts from nothing (a warm-up over its history) knows little about which
+    // of the positions in front of it are in the chains, and most tiles were parsed again four or five times before their neighbours' guesses had settled.  So only every
+    // K-th tile guesses; the K - 1 behind it are parsed one phase after the other, each from where the tile in front ended and with that tile's bits -- by the third or
+    // fourth of a run those are the stream's.  (1 + 1 / K) parses per tile instead of 2, and the rounds that follow start from a far better state; the price is K
+    // launches with 1 / K of the tiles each, so K grows with the batch.
+    uint32_t K = env_u32("ZGPU_FAST_RUN", 0);
+    if (K == 0) { K = nb / 256; if (K < 1) K = 1; if (K > 16) K = 16; } // (measured: 64 MiB 146 -> 108 ms with 8, 256 MiB 309 -> 170 with 16, 1 GiB 2029 -> 427; no gain below 16 MiB, where every launch is one tile's latency)
+    if (K > 64) K = 64;
+    if (K > 1) {
+        std::vector<uint32_t> all(nb);
+        uint32_t at = 0;
+        std::vector<uint32_t> start(K + 1, 0);
+        for (uint32_t p = 0; p < K; p++) { start[p] = at; for (uint32_t c = p; c < nb; c += K) all[at++] = c; }
+        start[K] = at;
+        ZGPU_HIP_CHECK(hipMemcpyAsync(e->cf_list_b, all.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st)); // (the vector goes out of scope)
+        for (uint32_t p = 0; p < K; p++) {
+            const uint32_t cnt = start[p + 1] - start[p];
+            if (!cnt) continue;
+            FastTiles ft{};
+            fill(ft, 0, e->cf_list_b + start[p]);
+            ft.warm_mode = p == 0;
+            launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, cnt, st);
+            launch_fast_flip_list(e->cf_cur, e->cf_exit_a, e->cf_exit_b, e->cf_list_b + start[p], cnt, st);
+            e->cf_tile_parses += cnt;
+        }
+        e->cf_rounds++;
+        // what the rounds start with: the run heads behind the first -- the tile in front of each was parsed after it
+        std::vector<uint32_t> heads;
+        std::vector<uint8_t> ab(nb, 0);
+        for (uint32_t c = K; c < nb; c += K) { heads.push_back(c); ab[c] = 1; }
+        if (heads.empty()) { launch_fast_finish(e->cf_cur, e->cf_exit_a, e->cf_ins0, e->cf_ins1, nb, tg.entry + g.chunk0 + nb, e->cf_prev, e->cf_prev2, g.chunk0 == 0 ? e->cf_hist : nullptr, st); return ZGPU_OK; }
+        ZGPU_HIP_CHECK(hipMemcpyAsync(e->cf_list_a, heads.data(), heads.size() * 4, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipMemcpyAsync(act, ab.data(), nb, hipMemcpyHostToDevice, st));
+        ZGPU_HIP_CHECK(hipStreamSynchronize(st));
+        if (trace) fprintf(stderr, "fast tiles: round 0 in %u phases, %zu run heads to parse again\n", K, heads.size());
+        list = e->cf_list_a; list_next = e->cf_list_b; ngrid = (uint32_t)heads.size();
+        e->cf_tile_parses += ngrid;
+    }
+    for (uint32_t round = K > 1 ? 1 : 0;; round++) {
+        FastTiles ft{};
+        fill(ft, round, list);
+        ft.warm_mode = round == 0;
+        if (ft.dbg) hipMemsetAsync(dbg, 0xff, (size_t)nb * 32, st);
         launch_lz_fastwin_tiles(g, tg, ft, cfg, S, ir, e->tokens, e->meta, ngrid, st);
         if (ft.dbg) {
             std::vector<uint32_t> h((size_t)nb * 8);

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
     constexpr int NW = NICE / 8;
     const uint32_t c = ft.list ? ft.list[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
-    const bool warm = ft.round == 0 && c != 0;
+    const bool warm = ft.warm_mode && c != 0;
     uint64_t wb; uint32_t n, h0, h1, nent;
     tile_span(g, tg, c, wb, n, h0, h1, nent);
     const uint8_t *src = g.in + wb;
@@ -821,6 +821,18 @@ __global__ void __launch_bounds__(256) fast_hist_kernel(const uint32_t *before, 
         v |= (on ? 1u : 0u) << b;
     }
     out[w] = v;
+}
+// behind a launch over a list of tiles that all make their new results current (the phases of round 0, zgpu_engine.hip lz_tiles_fast)
+__global__ void __launch_bounds__(256) fast_flip_list_kernel(uint8_t *cur, uint16_t *exit_cur, const uint16_t *exit_new, const uint32_t *list, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = list[i];
+    cur[c] ^= 1; exit_cur[c] = exit_new[c];
+}
+void launch_fast_flip_list(uint8_t *cur, uint16_t *exit_cur, const uint16_t *exit_new, const uint32_t *list, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(fast_flip_list_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, exit_cur, exit_new, list, n);
 }
 void launch_fast_init(uint8_t *cur, uint8_t *active, uint16_t *exit_cur, uint32_t n, hipStream_t st) { hipLaunchKernelGGL(fast_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cur, active, exit_cur, n); }
 void launch_fast_flip(uint8_t *cur, const uint8_t *active, uint8_t *active_next, const uint8_t *changed, uint16_t *exit_cur, const uint16_t *exit_new, uint32_t n, uint32_t round,
