@@ -64,6 +64,25 @@ def test_golden_streams_of_both_corpora_through_the_z_stream_api():
     assert not bad, bad[:10]
 
 
+def test_fast_levels_round_zero_in_phases(eng, monkeypatch):
+    """Levels 1-3: only every K-th tile of a batch starts from a guess, the K - 1 behind it are parsed phase by phase from the tile in front's results
+    (zgpu_engine.hip lz_tiles_fast; K = tiles / 256 by default, 1 for inputs this small).  Runs of 1, 3, 4 and 7 tiles over 3 MiB of both corpora and over data
+    whose parse never forgets where it started (a period, zeros): the restatement's bytes whatever K is."""
+    from zlib_amd import gpu
+    F = gpu.F_FINAL | gpu.F_CONTINUOUS
+    rnd = random.Random(11)
+    per = bytes(rnd.getrandbits(8) for _ in range(5000))
+    srcs = {"sil": corpus(0, 31, 3 << 20), "log": corpus(1, 32, 3 << 20), "per": (per * 700)[: 3 << 20], "zeros+": bytes(1 << 20) + corpus(0, 33, 1 << 20) + bytes(700000)}
+    for name, d in srcs.items():
+        for level in (1, 2, 3):
+            want = O.deflate_cont(d, level)
+            for k in ("1", "3", "4", "7"):
+                monkeypatch.setenv("ZGPU_FAST_RUN", k)
+                got = eng.deflate_host(d, level, flags=F)
+                assert got == want, (name, level, k, len(got), len(want))
+    monkeypatch.delenv("ZGPU_FAST_RUN")
+
+
 def test_engine_one_shot_against_the_restatement(eng):
     """zgpu_deflate_host(ZGPU_F_CONTINUOUS): sizes around the tiles' ranges (32512 positions each, the first 65024) and the window's slides, every level,
     strategies, several batches of tiles per feed."""
