@@ -411,9 +411,9 @@ def main():
 
             def f():
                 st["res"] = eng.deflate_device(src.data_ptr(), nbytes, level, cdst.data_ptr(), max(cap, ccap), flags=gpu.F_FINAL | gpu.F_ZLIB_WRAP | gpu.F_CONTINUOUS, stream=stream)
-            d, pr = timed(f, steps, 1)
+            d, pr = timed(f, steps, 2)  # (two untimed calls: the engine sizes its batches by the memory that is free, and grows them once more in the second call when this process holds a lot)
             out = {"metric": "GiB/s raw input compressed (deflate level %d), ONE continuous stream" % level, "value": round(nbytes * steps / d / 2**30, 4), "unit": "GiB/s",
-                   "steps": steps, "warmup": 1, "ms_per_step": round(d / steps * 1e3, 3), "compression_ratio": round(nbytes / st["res"].out_bytes, 4),
+                   "steps": steps, "warmup": 2, "ms_per_step": round(d / steps * 1e3, 3), "compression_ratio": round(nbytes / st["res"].out_bytes, 4),
                    "stream_bytes": int(st["res"].out_bytes), "roofline": roofline_of(pr, steps, nbytes, st["res"].out_bytes, "deflate-continuous", level)}
             try:
                 rows = [r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "continuous_kat.json")))["rows"]
