@@ -53,6 +53,9 @@ constexpr uint32_t kLBits = 9, kDBits = 9, kStageDwords = 256;
 #ifndef ZGPU_INF_RING
 #define ZGPU_INF_RING 32768
 #endif
+#ifndef ZGPU_INF_PARCOPY
+#define ZGPU_INF_PARCOPY 1 // the independent matches of a pass copied together (0: one after the other, A/B builds)
+#endif
 #ifndef ZGPU_INF_RING_DEFAULT_KB
 #define ZGPU_INF_RING_DEFAULT_KB 8 // the ring of chunks decoded straight into place (zgpu_inflate_device); ZGPU_INF_RING_KB at run time
 #endif
@@ -886,6 +889,30 @@ __global__ void __launch_bounds__(128, (!SPEC && RING <= 8192) ? 5 : 4) inflate_
                     if (sel_mask(take, k2, 0u) == 1) L.out[offv & (kOutRing - 1)] = (ring_t)(uint8_t)(tw >> 2);
                     INF_T(10);
                     uint64_t mm = take & __ballot(k2 == 2);
+                    if (ZGPU_INF_PARCOPY && !SPEC) {
+                        // The matches whose source ends in front of what this pass produces do not depend on each other or on the pass's literals: they are copied together, 64 bytes of
+                        // their concatenation a step -- byte b belongs to the first match whose running length exceeds b (a search over the lanes' prefix sums by shuffles) --
+                        // instead of one match after the other (most are under ten bytes: six lanes of 64 at work, 215 ns each at ten segments a CU).  The others -- a source inside the
+                        // pass's own output, a distance shorter than the length, a source that is read back from the destination -- follow in order as before.
+                        const uint32_t dist = (tw >> 11) + 1;
+                        const bool ind = ((take >> lane) & 1ull) && k2 == 2 && !(FAR && ((farm >> lane) & 1ull)) && dist >= (offv - o) + len;
+                        const uint64_t pm = __ballot(ind);
+                        if (__builtin_popcountll(pm) >= 2) {
+                            const uint32_t li = ind ? len : 0u, incl = wave_prefix_sum(li), T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            __builtin_amdgcn_wave_barrier();
+                            for (uint32_t it = 0; it < T; it += 64) {
+                                const uint32_t b = it + lane;
+                                uint32_t lo = 0, hi = 63;
+#pragma unroll
+                                for (int st = 0; st < 6; st++) { const uint32_t mid = (lo + hi) >> 1, v = (uint32_t)__shfl((int)incl, (int)mid); if (v > b) hi = mid; else lo = mid + 1; }
+                                const uint32_t im = (uint32_t)__shfl((int)incl, (int)lo), lm = (uint32_t)__shfl((int)li, (int)lo), om = (uint32_t)__shfl((int)offv, (int)lo), dm = (uint32_t)__shfl((int)dist, (int)lo);
+                                const uint32_t j = b - (im - lm);
+                                if (b < T) { const ring_t v = L.out[(om - dm + j) & (kOutRing - 1)]; L.out[(om + j) & (kOutRing - 1)] = v; }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            mm &= ~pm;
+                        }
+                    }
                     while (mm) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(mm); mm &= mm - 1;
                         const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)tw, (int)l), mo = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)l);
