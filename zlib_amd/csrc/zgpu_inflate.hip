@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(128, (!SPEC && RING <= 8192) ? 5 : 4) inflate_
                     if (sel_mask(take, k2, 0u) == 1) L.out[offv & (kOutRing - 1)] = (ring_t)(uint8_t)(tw >> 2);
                     INF_T(10);
                     uint64_t mm = take & __ballot(k2 == 2);
-                    if (ZGPU_INF_PARCOPY && !SPEC) {
+                    if (ZGPU_INF_PARCOPY) {
                         // The matches whose source ends in front of what this pass produces do not depend on each other or on the pass's literals: they are copied together, 64 bytes of
                         // their concatenation a step -- byte b belongs to the first match whose running length exceeds b (a search over the lanes' prefix sums by shuffles) --
                         // instead of one match after the other (most are under ten bytes: six lanes of 64 at work, 215 ns each at ten segments a CU).  The others -- a source inside the
