@@ -38,7 +38,7 @@ struct TreeWorkT {
     uint16_t freq[kNodes];
     uint16_t dad[kNodes];
     uint16_t len[kNodes];
-    __attribute__((aligned(8))) uint32_t heap[kNodes + 1]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order
+    __attribute__((aligned(16))) uint32_t heap[kNodes + 5]; // [1..heap_len]: packed entries; [heap_max..]: node numbers in extraction order (+4: the grandchildren read of sift_down may start at 2 * heap_len)
     uint16_t bl_count[kMaxBits + 1];
     uint16_t next_code[kMaxBits + 1];
 };
@@ -73,14 +73,24 @@ struct BitWriter {
 template <class TW>
 __device__ inline void sift_down(TW &t, int heap_len, int k) // pqdownheap, trees.c:461-478
 {
+    // Two levels per trip to LDS: the four grandchildren (16 bytes at 2 j) are read together with the two children, so the second of two steps decides from registers.
+    // The comparisons and their order are pqdownheap's; what is read past the heap's end is never looked at (the j <= heap_len / j < heap_len tests stand).
     const uint32_t v = t.heap[k];
     int j = k << 1;
     while (j <= heap_len) {
         const uint2 ch = *reinterpret_cast<const uint2 *>(&t.heap[j]); // children j and j+1 (j is even); j+1 may lie past the heap
-        uint32_t c = ch.x;
-        if (j < heap_len && (ch.y >> 10) <= (ch.x >> 10)) { c = ch.y; j++; }
+        const uint4 gc = *reinterpret_cast<const uint4 *>(&t.heap[2 * j]); // their children 2j .. 2j+3
+        uint32_t c = ch.x; int j1 = j;
+        if (j < heap_len && (ch.y >> 10) <= (ch.x >> 10)) { c = ch.y; j1 = j + 1; }
         if ((v >> 10) <= (c >> 10)) break;
-        t.heap[k] = c; k = j; j <<= 1;
+        t.heap[k] = c; k = j1;
+        const int j2 = j1 << 1;
+        if (j2 > heap_len) break;
+        const uint32_t g0 = j1 == j ? gc.x : gc.z, g1 = j1 == j ? gc.y : gc.w;
+        uint32_t c2 = g0; int j3 = j2;
+        if (j2 < heap_len && (g1 >> 10) <= (g0 >> 10)) { c2 = g1; j3 = j2 + 1; }
+        if ((v >> 10) <= (c2 >> 10)) break;
+        t.heap[k] = c2; k = j3; j = j3 << 1;
     }
     t.heap[k] = v;
 }
