@@ -278,7 +278,9 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
                 const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 65536) : env_u32("ZGPU_BATCH_CHUNKS", 65536); // (levels 1-3: see host_batch below)
                 if (per_launch && nch0 > per_launch) nch0 = per_launch;
             }
-            const uint64_t upto = cfg.chain == 4 ? 16384 : cfg.chain == 8 ? 16384 : 3072;
+            // (round 4: without the ring in LDS twelve chunks share a CU and the waves' form scales with the launch -- level 1: 1 GiB 58.6 ms against the loop's 150.9, 3 GiB 164 against 225,
+            // 4 GiB 217.6 against 213 with the hand-on; level 2: 2 GiB 160 against 208, 3 GiB 237 against 240; level 3: 256 MiB 110 against 149, 1 GiB 328 against 299)
+            const uint64_t upto = cfg.chain == 4 ? 61440 : cfg.chain == 8 ? 45056 : 10240;
             const char *ho = getenv("ZGPU_HAND_ON"); // 0: the loop keeps every chunk (A/B runs); 2: the loop + hand-on whatever the size of the call (tests)
             if (ho && ho[0] == '2' && auto_env == 0) hand_on = true;
             else if (nch0 <= upto || auto_env == ZGPU_LZ_FASTWIN) impl = ZGPU_LZ_FASTWIN;

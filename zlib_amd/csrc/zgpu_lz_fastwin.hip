@@ -75,6 +75,24 @@ __device__ inline void fw_ld64x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w) : "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
+// RING false (round 4): no copy of the chunk in LDS -- the bytes of a position and of its candidates come from the input itself (L2 / the Infinity Cache: a chunk's 64 KiB have just
+// been streamed by the sort), which leaves 13 KiB of LDS per chunk (the bits and the staged S entries) and lets twelve chunks share a CU where the 34 KiB ring allowed three
+struct __attribute__((packed, aligned(1))) FwU64 { uint64_t v; };
+constexpr uint32_t kFwOffFlagsNR = 0, kFwOffStgNR = (kFwFlagWords * 4 + 15) & ~15u, kFwLdsNR = kFwOffStgNR + 64 * kFwStgStride;
+__device__ inline uint64_t fw_g64(const uint8_t *src, uint32_t pos, uint64_t safe_end)
+{
+    if ((uint64_t)pos + 8 <= safe_end) return reinterpret_cast<const FwU64 *>(src + pos)->v;
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 8 && (uint64_t)pos + k < safe_end; k++) v |= (uint64_t)src[pos + k] << (8 * k);
+    return v;
+}
+__device__ inline uint32_t fw_g32(const uint8_t *src, uint32_t pos, uint64_t safe_end)
+{
+    if ((uint64_t)pos + 4 <= safe_end) return reinterpret_cast<const FwU32 *>(src + pos)->v;
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4 && (uint64_t)pos + k < safe_end; k++) v |= (uint32_t)src[pos + k] << (8 * k);
+    return v;
+}
 __device__ inline uint32_t fw_ring(uint32_t p) { const uint32_t d = p - kFwRing; return p < d ? p : d; } // p mod ring size, p < 2 * ring
 __device__ inline uint32_t fw_diff8(uint64_t x) { return x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u; }
 
@@ -87,13 +105,14 @@ __device__ __noinline__ uint4 fw_tail16(const uint8_t *in, uint32_t o, uint64_t 
 
 // CHAIN: max_chain_length; NICE: nice_match (a multiple of 8: the lanes compare that many bytes of every candidate, a match that reaches it is
 // measured by all lanes together when the walk takes it)
-template <int CHAIN, int NICE>
+template <int CHAIN, int NICE, bool RING>
 __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_insert, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
                                                       uint32_t *__restrict__ tokens, ChunkMeta *__restrict__ meta)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
     static_assert(NICE % 8 == 0 && NICE >= 8 && NICE <= 32 && CHAIN % 4 == 0, "whole groups of four candidates, whole 8-byte steps");
     constexpr int NW = NICE / 8;
+    constexpr uint32_t OFF_FLAGS = RING ? kFwOffFlags : kFwOffFlagsNR, OFF_STG = RING ? kFwOffStg : kFwOffStgNR;
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     uint64_t lo; uint32_t n;
     chunk_span(g, c, lo, n);
@@ -104,7 +123,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     const uint32_t cm = chunk_of(g, c); // (a launch over a list of chunks: input, tokens and meta are the listed chunk's, the sorted buckets are slot c's)
     uint32_t *tok = tokens + (size_t)cm * kChunkMax;
     const uint32_t base = chunk_base(g, c), npos = n >= 3 ? n - 2 : 0;
-    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + OFF_FLAGS);
     const uint32_t ring_a = fw_lds_base(fw_lds);
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
 
@@ -114,7 +133,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
     // ---- the ring: block k (1 KiB of the chunk) lives at (k mod 34) KiB ----
     uint32_t filled = 0;
     auto fill_to = [&](uint32_t need) { // (uniform)
-        while (filled < need) {
+        while (RING && filled < need) {
             const uint32_t o = filled + 16 * lane;
             uint4 v;
             if ((uint64_t)o + 16 <= safe_end) v = reinterpret_cast<const FwU128 *>(src + o)->v; else v = fw_tail16(src, o, safe_end);
@@ -162,10 +181,10 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
         const uint32_t w0 = win * 64, p = w0 + lane;
         const bool skip = pos >= w0 + 64; // the window lies inside a match (a long one: a short one ends within six positions)
         if (!skip) { // the staged entries of this window
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride) = sq0;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 16) = sq1;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 32) = sq2;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 48) = sq3;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 16) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 32) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 48) = sq3;
         }
         const uint32_t iv = ir_cur;
         load_s(ir_nxt);
@@ -186,9 +205,14 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
         const uint32_t cmp_max = cap < (uint32_t)NICE ? cap : (uint32_t)NICE;
         const int w = (int)(p + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
         uint64_t own[NW];
-        const uint32_t own_a = ring_a + fw_ring(p);
-        if (NW == 1) own[0] = fw_ld64(own_a);
-        else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        if (!RING) {
+#pragma unroll
+            for (int t = 0; t < NW; t++) own[t] = fw_g64(src, p + 8 * t, safe_end);
+        } else {
+            const uint32_t own_a = ring_a + fw_ring(p);
+            if (NW == 1) own[0] = fw_ld64(own_a);
+            else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        }
         const uint32_t own_byte = (uint32_t)own[0] & 255u;
 
         uint32_t res = 1, mstart = 0, mex = 0; // this lane's search: length | kResTerm | kResInc; where the match starts; the bits it examined
@@ -221,9 +245,14 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
 #pragma unroll
                         for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + kFwOffStg + lane * kFwStgStride + 62 - 2 * k[u]);
+                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + lane * kFwStgStride + 62 - 2 * k[u]);
                         uint64_t cb[4][NW];
-                        {
+                        if (!RING) {
+#pragma unroll
+                            for (int t = 0; t < NW; t++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) cb[u][t] = fw_g64(src, q[u] + 8 * t, safe_end);
+                        } else {
                             const uint32_t a0 = ring_a + fw_ring(q[0]), a1 = ring_a + fw_ring(q[1]), a2 = ring_a + fw_ring(q[2]), a3 = ring_a + fw_ring(q[3]);
 #pragma unroll
                             for (int t = 0; t < NW; t++) fw_ld64x4(a0 + 8 * t, a1 + 8 * t, a2 + 8 * t, a3 + 8 * t, cb[0][t], cb[1][t], cb[2][t], cb[3][t]);
@@ -276,7 +305,8 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                     const uint32_t p0 = w0 + L, q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
                     const uint32_t o = NICE + 4 * lane;
                     uint32_t xa, xb;
-                    fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
+                    if (!RING) { xa = fw_g32(src, q0 + o, safe_end); xb = fw_g32(src, p0 + o, safe_end); }
+                    else fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
                     xa ^= xb;
                     const uint64_t ne = __builtin_amdgcn_ballot_w64(xa != 0);
                     uint32_t len = cap0;
@@ -359,7 +389,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
                     uint32_t l = 0;
                     if (ins && (int)(q + base) > limit0 - 1) { // (a candidate out of reach is turned away before its length is asked for; its bytes may have left the ring)
                         for (;;) {
-                            const uint32_t d = fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l)));
+                            const uint32_t d = RING ? fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l))) : fw_diff8(fw_g64(src, q + l, safe_end) ^ fw_g64(src, p0 + l, safe_end));
                             l += d;
                             if (d < 8 || l >= cap0) break;
                         }
@@ -400,12 +430,13 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
 //   ins (per tile, two buffers): one bit per local position 32512 .. 65535: "in the chains", valid below the tile's exit -- read by the tile behind it,
 //   for which these are its local positions 0 .. 33023.
 // Block cuts, the window's slides and the stored-block veto are the stream's business (cont_table_kernel), not the tile's.
-template <int CHAIN, int NICE>
+template <int CHAIN, int NICE, bool RING>
 __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom tg, FastTiles ft, uint32_t max_insert, const uint16_t *__restrict__ S_all, const uint32_t *__restrict__ ir_all,
                                                            uint32_t *__restrict__ tokens, ChunkMeta *__restrict__ meta)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t fw_lds[];
     constexpr int NW = NICE / 8;
+    constexpr uint32_t OFF_FLAGS = RING ? kFwOffFlags : kFwOffFlagsNR, OFF_STG = RING ? kFwOffStg : kFwOffStgNR;
     const uint32_t c = ft.list ? ft.list[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
     const bool warm = ft.warm_mode && c != 0;
     uint64_t wb; uint32_t n, h0, h1, nent;
@@ -417,7 +448,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
     uint32_t *tok = tokens + (size_t)c * kChunkMax;
     const uint32_t base = (tg.abs0_nil && tg.abs0 + wb == 0) ? 0u : 1u, npos = n >= 3 ? n - 2 : 0;
     const uint32_t nil_local = (tg.nil_pos >= wb && tg.nil_pos - wb < kChunkMax) ? (uint32_t)(tg.nil_pos - wb) : ~0u;
-    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + kFwOffFlags);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(fw_lds + OFF_FLAGS);
     const uint32_t ring_a = fw_lds_base(fw_lds);
     const uint64_t lane_bit = 1ull << lane, lanes_below = lane_bit - 1;
     const uint32_t entry_pos = warm ? 0u : (c == 0 ? h0 + tg.entry[g.chunk0] : kTileStride + ft.exit_cur[c - 1]); // where this parse starts (the batch's first tile: the chain's hand-over)
@@ -464,7 +495,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
 
     uint32_t filled = 0;
     auto fill_to = [&](uint32_t need) {
-        while (filled < need) {
+        while (RING && filled < need) {
             const uint32_t o = filled + 16 * lane;
             uint4 v;
             if ((uint64_t)o + 16 <= safe_end) v = reinterpret_cast<const FwU128 *>(src + o)->v; else v = fw_tail16(src, o, safe_end);
@@ -501,10 +532,10 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
         const uint32_t w0 = win * 64, p = w0 + lane;
         const bool skip = pos >= w0 + 64;
         if (!skip) {
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride) = sq0;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 16) = sq1;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 32) = sq2;
-            *reinterpret_cast<uint4 *>(fw_lds + kFwOffStg + lane * kFwStgStride + 48) = sq3;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 16) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 32) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 48) = sq3;
         }
         const uint32_t iv = ir_cur;
         load_s(ir_nxt);
@@ -523,9 +554,14 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
         const uint32_t cmp_max = cap < (uint32_t)NICE ? cap : (uint32_t)NICE;
         const int w = (int)(p + base), limit = w > (int)kMaxDist ? w - (int)kMaxDist : 0;
         uint64_t own[NW];
-        const uint32_t own_a = ring_a + fw_ring(p);
-        if (NW == 1) own[0] = fw_ld64(own_a);
-        else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        if (!RING) {
+#pragma unroll
+            for (int t = 0; t < NW; t++) own[t] = fw_g64(src, p + 8 * t, safe_end);
+        } else {
+            const uint32_t own_a = ring_a + fw_ring(p);
+            if (NW == 1) own[0] = fw_ld64(own_a);
+            else { fw_ld64x2(own_a, own_a + 8, own[0], own[1]); if (NW == 4) fw_ld64x2(own_a + 16, own_a + 24, own[2], own[3]); }
+        }
         const uint32_t own_byte = (uint32_t)own[0] & 255u;
 
         uint32_t res = 1, mstart = 0, mex = 0;
@@ -556,9 +592,14 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
 #pragma unroll
                         for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + kFwOffStg + lane * kFwStgStride + 62 - 2 * k[u]);
+                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + lane * kFwStgStride + 62 - 2 * k[u]);
                         uint64_t cb[4][NW];
-                        {
+                        if (!RING) {
+#pragma unroll
+                            for (int t = 0; t < NW; t++)
+#pragma unroll
+                                for (int u = 0; u < 4; u++) cb[u][t] = fw_g64(src, q[u] + 8 * t, safe_end);
+                        } else {
                             const uint32_t a0 = ring_a + fw_ring(q[0]), a1 = ring_a + fw_ring(q[1]), a2 = ring_a + fw_ring(q[2]), a3 = ring_a + fw_ring(q[3]);
 #pragma unroll
                             for (int t = 0; t < NW; t++) fw_ld64x4(a0 + 8 * t, a1 + 8 * t, a2 + 8 * t, a3 + 8 * t, cb[0][t], cb[1][t], cb[2][t], cb[3][t]);
@@ -604,7 +645,8 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
                     const uint32_t p0 = w0 + L, q0 = __builtin_amdgcn_readlane(mstart, L), cap0 = n - p0 < kMaxMatch ? n - p0 : kMaxMatch;
                     const uint32_t o = NICE + 4 * lane;
                     uint32_t xa, xb;
-                    fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
+                    if (!RING) { xa = fw_g32(src, q0 + o, safe_end); xb = fw_g32(src, p0 + o, safe_end); }
+                    else fw_ld32x2(ring_a + fw_ring(q0 + o), ring_a + fw_ring(p0 + o), xa, xb);
                     xa ^= xb;
                     const uint64_t ne = __builtin_amdgcn_ballot_w64(xa != 0);
                     uint32_t len = cap0;
@@ -680,7 +722,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
                     uint32_t l = 0;
                     if (ins && (int)(q + base) > limit0 - 1) {
                         for (;;) {
-                            const uint32_t d = fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l)));
+                            const uint32_t d = RING ? fw_diff8(fw_ld64(pa + fw_ring(q + l)) ^ fw_ld64(pa + fw_ring(p0 + l))) : fw_diff8(fw_g64(src, q + l, safe_end) ^ fw_g64(src, p0 + l, safe_end));
                             l += d;
                             if (d < 8 || l >= cap0) break;
                         }
@@ -756,6 +798,14 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
     }
 }
 
+// Which form a launch takes: with fewer chunks than three per CU the ring form (a chunk 5.1 ms instead of 5.6: its latency is what a small call pays), from there on the one
+// without the ring (twelve chunks per CU: 256 MiB 32.9 -> 19.3 ms, 1 GiB 116 -> 59, 4 GiB 450 -> 217 at level 1).  ZGPU_FW_RING=1 / 0 forces one of them.
+static bool fw_use_ring(uint32_t nlaunch)
+{
+    static int v = -2;
+    if (v == -2) { const char *e = getenv("ZGPU_FW_RING"); v = e ? atoi(e) : -1; }
+    return v < 0 ? nlaunch < 768 : v != 0;
+}
 // the levels' own parameters only (deflate.c:137-149): a tuned stream goes to the lane-per-chunk loop
 bool lz_fastwin_serves(const LevelCfg &cfg)
 {
@@ -767,14 +817,20 @@ void launch_lz_fastwin(const ChunkGeom &g, LevelCfg cfg, const uint16_t *S, cons
 {
     static bool opt_in = false;
     if (!opt_in) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<8, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_kernel<32, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
         opt_in = true;
     }
-    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_kernel<4, 8>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
-    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_kernel<8, 16>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
-    else hipLaunchKernelGGL((fastwin_kernel<32, 32>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+    if (!fw_use_ring(g.nchunks)) {
+        if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_kernel<4, 8, false>), dim3(g.nchunks), dim3(64), kFwLdsNR, st, g, cfg.lazy, S, ir, tokens, meta);
+        else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_kernel<8, 16, false>), dim3(g.nchunks), dim3(64), kFwLdsNR, st, g, cfg.lazy, S, ir, tokens, meta);
+        else hipLaunchKernelGGL((fastwin_kernel<32, 32, false>), dim3(g.nchunks), dim3(64), kFwLdsNR, st, g, cfg.lazy, S, ir, tokens, meta);
+        return;
+    }
+    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_kernel<4, 8, true>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_kernel<8, 16, true>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
+    else hipLaunchKernelGGL((fastwin_kernel<32, 32, true>), dim3(g.nchunks), dim3(64), kFwLds, st, g, cfg.lazy, S, ir, tokens, meta);
 }
 
 // ---- the rounds' bookkeeping (one lane per tile) ----
@@ -857,14 +913,20 @@ void launch_lz_fastwin_tiles(const ChunkGeom &g0, const TileGeom &tg, const Fast
     ChunkGeom g = g0; // (g.nchunks stays the batch's: the launch is over `ngrid` of its tiles)
     static bool opt_in = false;
     if (!opt_in) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<32, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<8, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fastwin_tile_kernel<32, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwLds);
         opt_in = true;
     }
-    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
-    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
-    else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    if (!fw_use_ring(ngrid)) {
+        if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8, false>), dim3(ngrid), dim3(64), kFwLdsNR, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+        else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16, false>), dim3(ngrid), dim3(64), kFwLdsNR, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+        else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32, false>), dim3(ngrid), dim3(64), kFwLdsNR, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+        return;
+    }
+    if (cfg.chain == 4) hipLaunchKernelGGL((fastwin_tile_kernel<4, 8, true>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else if (cfg.chain == 8) hipLaunchKernelGGL((fastwin_tile_kernel<8, 16, true>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
+    else hipLaunchKernelGGL((fastwin_tile_kernel<32, 32, true>), dim3(ngrid), dim3(64), kFwLds, st, g, tg, ft, cfg.lazy, S, ir, tokens, meta);
 }
 
 } // namespace zgpu
