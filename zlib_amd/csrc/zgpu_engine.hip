@@ -645,7 +645,8 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
         if (ft.dbg) {
             std::vector<uint32_t> h((size_t)nb * 8);
             hipMemcpyAsync(h.data(), dbg, (size_t)nb * 32, hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
-            for (uint32_t c = 0; c < nb && c < 40; c++) if (h[c * 8] != 0xffffffffu)
+            uint32_t shown = 0;
+            for (uint32_t c = 0; c < nb && shown < 6; c++) if (h[c * 8] != 0xffffffffu && ++shown)
                 fprintf(stderr, "   tile %u: %u words differ (%u .. %u), exit %u (was %u), entry %u, %u tokens\n", c, h[c * 8 + 1], h[c * 8 + 2], h[c * 8 + 3], h[c * 8 + 4], h[c * 8 + 5], h[c * 8 + 6], h[c * 8 + 7]);
         }
         launch_fast_flip(e->cf_cur, act, act_next, e->cf_changed, e->cf_exit_a, e->cf_exit_b, nb, round, e->cf_count, list_next, ft.kept, st);
@@ -664,9 +665,11 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
             active = nb - 1;
         }
         if (trace) {
+            static double t_last = 0; timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); const double t_now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+            fprintf(stderr, "[%.2f ms since the last round's end] ", t_now - t_last); t_last = t_now;
             uint32_t hs[8] = {};
             hipMemcpy(hs, dstat, 32, hipMemcpyDeviceToHost);
-            fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again (this round: %u entered where they had, %u stopped early, %u met a different token, %u had changes within reach to the end)\n", round, active, nb, hs[0], hs[1], hs[2], hs[3]);
+            fprintf(stderr, "fast tiles: round %u, %u of %u tiles to parse again (this round: %u entered where they had, %u stopped early, %u met a different token, %u had changes within reach to the end; first different token after %u of %u windows)\n", round, active, nb, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
         }
         if (active == 0) break;
         e->cf_tile_parses += active;

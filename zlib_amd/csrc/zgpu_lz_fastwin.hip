@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
                     if (stop_at != ~0u && same) neq = ti >= old_ntok || tok[ti] != nv;
                     tok[ti] = nv;
                 }
-                if (stop_at != ~0u && same && __builtin_amdgcn_ballot_w64(neq) != 0) { same = false; if (ft.stat && lane == 0) atomicAdd(&ft.stat[2], 1u); }
+                if (stop_at != ~0u && same && __builtin_amdgcn_ballot_w64(neq) != 0) { same = false; if (ft.stat && lane == 0) { atomicAdd(&ft.stat[2], 1u); atomicAdd(&ft.stat[4], (w0 - (entry_pos & ~63u)) >> 6); atomicAdd(&ft.stat[5], (h1 - entry_pos) >> 6); } }
                 if (ent_used == ~0u && Tv != 0) { ent_used = w0 + (uint32_t)__builtin_ctzll(Tv) - h0; if (stop_at != ~0u && ent_used != old_ent) same = false; }
                 ntok += (uint32_t)__builtin_popcountll(Tv);
             }
