@@ -278,7 +278,7 @@ static int deflate_device(zgpu_engine *e, const uint8_t *d_in, uint64_t in_bytes
                 const uint64_t per_launch = h_src ? env_u32("ZGPU_HOST_BATCH", 65536) : env_u32("ZGPU_BATCH_CHUNKS", 65536); // (levels 1-3: see host_batch below)
                 if (per_launch && nch0 > per_launch) nch0 = per_launch;
             }
-            // (round 4: without the ring in LDS twelve chunks share a CU and the waves' form scales with the launch -- level 1: 1 GiB 58.6 ms against the loop's 150.9, 3 GiB 164 against 225,
+            // (round 4: without the ring in LDS eleven chunks share a CU and the waves' form scales with the launch -- level 1: 1 GiB 58.6 ms against the loop's 150.9, 3 GiB 164 against 225,
             // 4 GiB 217.6 against 213 with the hand-on; level 2: 2 GiB 160 against 208, 3 GiB 237 against 240; level 3: 256 MiB 110 against 149, 1 GiB 328 against 299)
             const uint64_t upto = cfg.chain == 4 ? 61440 : cfg.chain == 8 ? 45056 : 10240;
             const char *ho = getenv("ZGPU_HAND_ON"); // 0: the loop keeps every chunk (A/B runs); 2: the loop + hand-on whatever the size of the call (tests)
@@ -604,6 +604,9 @@ static int lz_tiles_fast(zgpu_engine *e, const ChunkGeom &g, const TileGeom &tg,
     // launches with 1 / K of the tiles each, so K grows with the batch.
     uint32_t K = env_u32("ZGPU_FAST_RUN", 0);
     if (K == 0) { K = nb / 256; if (K < 1) K = 1; if (K > 16) K = 16; } // (measured: 64 MiB 146 -> 108 ms with 8, 256 MiB 309 -> 170 with 16, 1 GiB 2029 -> 427; no gain below 16 MiB, where every launch is one tile's latency)
+    // ... and no phase larger than the chip holds at once: eleven one-wave workgroups of 13.3 KiB LDS a CU are 2 816 tiles, a phase of 4 128 (a batch of 66 052 in 16) runs as two
+    // waves of workgroups, the second a third full -- 4 GiB at level 1: 16 phases 672 ms, 22 (3 003 tiles each) 673, 24 (2 752) 577, 32 654, 44 711
+    if (env_u32("ZGPU_FAST_RUN", 0) == 0) { const uint32_t kw = (nb + 2751) / 2752; if (kw > K) K = kw; }
     if (K > 64) K = 64;
     if (K > 1) {
         std::vector<uint32_t> all(nb);
@@ -703,15 +706,28 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
     const uint64_t ntiles = end > e0 ? (end <= w0 + kTileH1 ? 1 : (end - w0 - kTileH1 + kTileStride - 1) / kTileStride + 1) : 0;
     if (!ends && ntiles == 0) { res->out_bytes = 0; res->nchunks = 0; res->ntokens = 0; res->adler32 = 1; res->crc32 = 0; res->data_type = cs->data_type; if (f.check_from < f.buf_bytes) return fail(e, ZGPU_STREAM_ERROR, "continuous stream: a feed that parses nothing brings no bytes"); return ZGPU_OK; }
     uint32_t batch_max = env_u32("ZGPU_CONT_BATCH_TILES", fast_lz ? 65536 : 32768); // (levels 1-3: every batch ends with a tail of rounds that are one tile's latency each, 4 GiB 1395 -> 1149 ms with twice the batch)
+    uint32_t batch_fit = ~0u; // what the device's memory admits
     {
         size_t free_b = 0, total_b = 0;
         const size_t per_tile = lz_sorted_workspace_bytes(1) + (size_t)kChunkMax * 4 + (size_t)(kTileStride + kTileSlack) * 4 + 3 * (size_t)kSlotStride + kSlotStride;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = (size_t)e->ct_tiles * per_tile;
+            // what this engine holds already and would use again, piece by piece (the chunked path's buffers serve the tiles too): counted as free, or the batch would
+            // grow from call to call as more of the same memory is held -- and a later call of a series would stop to allocate (seen in bench.py: 44 035, 64 837, 66 052 tiles)
+            const size_t held = (size_t)e->batch_cap * ((size_t)kChunkMax * 4 + kSlotStride) + (size_t)e->par_cap * lz_sorted_workspace_bytes(1) + (size_t)e->ct_tiles * ((size_t)(kTileStride + kTileSlack) * 4 + 3 * (size_t)kSlotStride);
             size_t fit = (free_b + held) / 10 * 6 / per_tile;
             if (fit < 64) fit = 64;
             if (fit < batch_max) batch_max = (uint32_t)fit;
+            batch_fit = fit < 0xffffffffull ? (uint32_t)fit : ~0u;
         }
+    }
+    // levels 1-3: no short batch at the end -- its tail of rounds is as long as a full batch's (2 GiB are 66 052 tiles: one batch, not 65 536 + 516; 4 GiB two of 66 052, not
+    // two and 1 032 tiles that take 70 ms).  A remainder below an eighth of a batch is spread over the others if memory admits it, and the batches are of one size.
+    if (fast_lz && ntiles > batch_max && !getenv("ZGPU_CONT_BATCH_TILES")) {
+        uint64_t nbat = (ntiles + batch_max - 1) / batch_max;
+        const uint64_t rem = ntiles % batch_max;
+        if (rem && rem < batch_max / 8) nbat--;
+        const uint64_t even = (ntiles + nbat - 1) / nbat;
+        if (even <= batch_fit) batch_max = (uint32_t)even;
     }
     // levels 4-9, more than one batch: two sets of per-batch buffers, half a batch each -- batch k's tokens, blocks and bits are made on a second stream
     // while batch k + 1 is sorted and walked on the first (ZGPU_CONT_PIPE=0: one after the other, for A/B runs)
@@ -725,9 +741,13 @@ static int deflate_cont(zgpu_engine *e, const ContFeed &f, const LevelCfg &cfg, 
         if (want >= 1024 && want < batch_max) batch_max = (uint32_t)want;
     }
     const uint32_t batch = (uint32_t)(ntiles < batch_max ? (ntiles ? ntiles : 1) : batch_max);
+    const bool size_trace = getenv("ZGPU_FAST_TRACE") != nullptr;
+    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    if (size_trace) fprintf(stderr, "continuous stream: %llu tiles, memory admits %u, batches of %u (held: %u tiles, %u chunks of tokens, %u of buckets)\n", (unsigned long long)ntiles, batch_fit, batch, e->ct_tiles, e->batch_cap, e->par_cap);
     int rc = ensure_deflate_ws(e, pipe ? 2 * batch + 1 : batch, false, 1);
     if (rc) return rc;
     if ((rc = ensure_cont_ws(e, pipe ? 2 * batch : batch, ntiles))) return rc;
+    if (size_trace) { timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1); fprintf(stderr, "continuous stream: workspaces in %.1f ms\n", (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6); }
     if (pipe && !e->ct_stream) {
         ZGPU_HIP_CHECK(hipStreamCreateWithFlags(&e->ct_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) { ZGPU_HIP_CHECK(hipEventCreateWithFlags(&e->ct_ev_a[i], hipEventDisableTiming)); ZGPU_HIP_CHECK(hipEventCreateWithFlags(&e->ct_ev_b[i], hipEventDisableTiming)); }

@@ -76,9 +76,9 @@ __device__ inline void fw_ld64x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
                  : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w) : "v"(a), "v"(b), "v"(c), "v"(d) : "memory");
 }
 // RING false (round 4): no copy of the chunk in LDS -- the bytes of a position and of its candidates come from the input itself (L2 / the Infinity Cache: a chunk's 64 KiB have just
-// been streamed by the sort), which leaves 13 KiB of LDS per chunk (the bits and the staged S entries) and lets twelve chunks share a CU where the 34 KiB ring allowed three
+// been streamed by the sort), which leaves 13 KiB of LDS per chunk (the bits and the staged S entries) and lets eleven chunks share a CU where the 34 KiB ring allowed three
 struct __attribute__((packed, aligned(1))) FwU64 { uint64_t v; };
-constexpr uint32_t kFwOffFlagsNR = 0, kFwOffStgNR = (kFwFlagWords * 4 + 15) & ~15u, kFwLdsNR = kFwOffStgNR + 64 * kFwStgStride;
+constexpr uint32_t kFwOffFlagsNR = 0, kFwOffStgNR = (kFwFlagWords * 4 + 15) & ~15u, kFwLdsNR = kFwOffStgNR + 63 * kFwStgStride + 64; // (13 312 bytes, without the last lane's padding.  ELEVEN workgroups run on a CU, not the twelve that 160 KiB / 13 KiB promise: a launch of 3 003 tiles takes two waves of workgroups' time, one of 2 752 one -- zgpu_engine.hip lz_tiles_fast)
 __device__ inline uint64_t fw_g64(const uint8_t *src, uint32_t pos, uint64_t safe_end)
 {
     if ((uint64_t)pos + 8 <= safe_end) return reinterpret_cast<const FwU64 *>(src + pos)->v;
@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
 }
 
 // Which form a launch takes: with fewer chunks than three per CU the ring form (a chunk 5.1 ms instead of 5.6: its latency is what a small call pays), from there on the one
-// without the ring (twelve chunks per CU: 256 MiB 32.9 -> 19.3 ms, 1 GiB 116 -> 59, 4 GiB 450 -> 217 at level 1).  ZGPU_FW_RING=1 / 0 forces one of them.
+// without the ring (eleven chunks per CU: 256 MiB 32.9 -> 19.3 ms, 1 GiB 116 -> 59, 4 GiB 450 -> 217 at level 1).  ZGPU_FW_RING=1 / 0 forces one of them.
 static bool fw_use_ring(uint32_t nlaunch)
 {
     static int v = -2;
