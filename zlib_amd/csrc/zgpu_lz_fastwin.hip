@@ -78,7 +78,11 @@ __device__ inline void fw_ld64x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
 // RING false (round 4): no copy of the chunk in LDS -- the bytes of a position and of its candidates come from the input itself (L2 / the Infinity Cache: a chunk's 64 KiB have just
 // been streamed by the sort), which leaves 13 KiB of LDS per chunk (the bits and the staged S entries) and lets eleven chunks share a CU where the 34 KiB ring allowed three
 struct __attribute__((packed, aligned(1))) FwU64 { uint64_t v; };
-constexpr uint32_t kFwOffFlagsNR = 0, kFwOffStgNR = (kFwFlagWords * 4 + 15) & ~15u, kFwLdsNR = kFwOffStgNR + 63 * kFwStgStride + 64; // (13 312 bytes, without the last lane's padding.  ELEVEN workgroups run on a CU, not the twelve that 160 KiB / 13 KiB promise: a launch of 3 003 tiles takes two waves of workgroups' time, one of 2 752 one -- zgpu_engine.hip lz_tiles_fast)
+#ifndef ZGPU_FW_STG64
+#define ZGPU_FW_STG64 0 // 1 (built at the end of round 4, scripts/build_variant.sh stg64 -DZGPU_FW_STG64=1): the staged entries of the form without the ring at 64 bytes a lane, slots swizzled -- 12 304 bytes a
+                        // workgroup, TWELVE to a CU (LDS is handed out in pieces of 1 280 bytes): 4 GiB level 1 in 22 phases 673 -> 564 ms, parity tests of levels 1-3 pass; not the default before the whole suite has run on it
+#endif
+constexpr uint32_t kFwOffFlagsNR = 0, kFwOffStgNR = (kFwFlagWords * 4 + 15) & ~15u, kFwLdsNR = kFwOffStgNR + (ZGPU_FW_STG64 ? 64 * 64 : 63 * kFwStgStride + 64); // (13 312 bytes, without the last lane's padding.  ELEVEN workgroups run on a CU, not the twelve that 160 KiB / 13 KiB promise: a launch of 3 003 tiles takes two waves of workgroups' time, one of 2 752 one -- zgpu_engine.hip lz_tiles_fast)
 __device__ inline uint64_t fw_g64(const uint8_t *src, uint32_t pos, uint64_t safe_end)
 {
     if ((uint64_t)pos + 8 <= safe_end) return reinterpret_cast<const FwU64 *>(src + pos)->v;
@@ -94,6 +98,13 @@ __device__ inline uint32_t fw_g32(const uint8_t *src, uint32_t pos, uint64_t saf
     return v;
 }
 __device__ inline uint32_t fw_ring(uint32_t p) { const uint32_t d = p - kFwRing; return p < d ? p : d; } // p mod ring size, p < 2 * ring
+// Byte offset of 16-byte slot j (0 .. 3) of a lane's 64 bytes of staged S entries.  At 80 bytes a lane the 16-byte stores of neighbouring lanes fall into different banks; at 64
+// (ZGPU_FW_STG64, the form without the ring only) the slot number is swizzled by the lane's instead.
+template <bool RING> __device__ inline uint32_t fw_stg_slot(uint32_t lane, uint32_t j)
+{
+    if (RING || !ZGPU_FW_STG64) return lane * kFwStgStride + 16u * j;
+    return lane * 64u + 16u * (j ^ ((lane >> 1) & 3u));
+}
 __device__ inline uint32_t fw_diff8(uint64_t x) { return x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u; }
 
 __device__ __noinline__ uint4 fw_tail16(const uint8_t *in, uint32_t o, uint64_t safe_end)
@@ -181,10 +192,10 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
         const uint32_t w0 = win * 64, p = w0 + lane;
         const bool skip = pos >= w0 + 64; // the window lies inside a match (a long one: a short one ends within six positions)
         if (!skip) { // the staged entries of this window
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride) = sq0;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 16) = sq1;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 32) = sq2;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 48) = sq3;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 0)) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 1)) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 2)) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 3)) = sq3;
         }
         const uint32_t iv = ir_cur;
         load_s(ir_nxt);
@@ -245,7 +256,7 @@ __global__ void __launch_bounds__(64) fastwin_kernel(ChunkGeom g, uint32_t max_i
 #pragma unroll
                         for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + lane * kFwStgStride + 62 - 2 * k[u]);
+                        for (int u = 0; u < 4; u++) { const uint32_t o = 62u - 2u * k[u]; q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, o >> 4) + (o & 15u)); }
                         uint64_t cb[4][NW];
                         if (!RING) {
 #pragma unroll
@@ -532,10 +543,10 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
         const uint32_t w0 = win * 64, p = w0 + lane;
         const bool skip = pos >= w0 + 64;
         if (!skip) {
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride) = sq0;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 16) = sq1;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 32) = sq2;
-            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + lane * kFwStgStride + 48) = sq3;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 0)) = sq0;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 1)) = sq1;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 2)) = sq2;
+            *reinterpret_cast<uint4 *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, 3)) = sq3;
         }
         const uint32_t iv = ir_cur;
         load_s(ir_nxt);
@@ -592,7 +603,7 @@ __global__ void __launch_bounds__(64) fastwin_tile_kernel(ChunkGeom g, TileGeom 
 #pragma unroll
                         for (int u = 0; u < 4; u++) { v[u] = m != 0; k[u] = v[u] ? (uint32_t)__builtin_ctz(m) : 0u; m &= m - 1u; }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + lane * kFwStgStride + 62 - 2 * k[u]);
+                        for (int u = 0; u < 4; u++) { const uint32_t o = 62u - 2u * k[u]; q[u] = *reinterpret_cast<const uint16_t *>(fw_lds + OFF_STG + fw_stg_slot<RING>(lane, o >> 4) + (o & 15u)); }
                         uint64_t cb[4][NW];
                         if (!RING) {
 #pragma unroll
